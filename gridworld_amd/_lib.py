@@ -1,0 +1,88 @@
+"""ctypes binding of the C ABI in include/igw.h (libigw_hip.so, built by gridworld_amd/build.py).
+
+There is NO CPU fallback: if the library cannot be loaded or no HIP device exists, every
+entry point raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libigw_hip.so')
+
+GRID_STRIDE = 1104
+CELLS = 1089
+AGENT_BYTES = 64
+TASK_META_BYTES = 128
+STAT_STRIPES = 64
+STAT_CHANGED, STAT_RESETS, STAT_STEPS = 0, 1, 2
+WALKING_DISCRETE, FLYING = 0, 1
+RESET_KEEP_SIZE = 1
+
+# every symbol include/igw.h declares (checked by tests/test_abi.py)
+EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy',
+           'igw_bind_buffers', 'igw_prepare_tasks', 'igw_reset', 'igw_step_walking', 'igw_step_flying',
+           'igw_rollout_walking', 'igw_fill_actions_walking', 'igw_task_eval']
+
+
+class IgwError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [('device', C.c_int32), ('num_envs', C.c_int32), ('num_tasks', C.c_int32),
+                ('action_space', C.c_int32), ('select_and_place', C.c_int32), ('size_reward', C.c_int32),
+                ('max_steps', C.c_int32), ('autoreset', C.c_int32),
+                ('right_placement_scale', C.c_double), ('wrong_placement_scale', C.c_double),
+                ('lanes_per_env', C.c_int32), ('reserved', C.c_int32)]
+
+
+class Buffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('grid', 'agent', 'env_task', 'task_target', 'task_start',
+                                          'task_meta', 'agent_pos', 'inventory', 'compass', 'reward',
+                                          'done', 'stats')]
+
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Loads libigw_hip.so (building it with hipcc first if it is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        from . import build as _build
+        try:
+            _build.build()
+        except Exception as e:  # stale .so + no hipcc is still usable; a missing .so is fatal
+            if not os.path.exists(LIB_PATH):
+                raise IgwError(f'libigw_hip.so is missing and could not be built: {e}') from e
+    if not os.path.exists(LIB_PATH):
+        raise IgwError('libigw_hip.so not found; run `python -m gridworld_amd.build`')
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    L.igw_version.restype = C.c_int
+    L.igw_last_error.restype = C.c_char_p
+    L.igw_device_count.restype = C.c_int
+    L.igw_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.igw_destroy.argtypes = [vp]
+    L.igw_bind_buffers.argtypes = [vp, C.POINTER(Buffers)]
+    L.igw_prepare_tasks.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.igw_reset.argtypes = [vp, vp, i32, vp]
+    L.igw_step_walking.argtypes = [vp, vp, vp]
+    L.igw_step_flying.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.igw_rollout_walking.argtypes = [vp, i64, u64, i64, i64, vp]
+    L.igw_fill_actions_walking.argtypes = [vp, vp, i64, i64, u64, i64, vp]
+    L.igw_task_eval.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    for name in EXPORTS:
+        getattr(L, name)
+        if name not in ('igw_last_error',):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(code, what=''):
+    if code != 0:
+        msg = load().igw_last_error()
+        raise IgwError(f'{what} failed ({code}): {msg.decode() if msg else ""}')

@@ -1,0 +1,49 @@
+"""Builds gridworld_amd/libigw_hip.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+    python -m gridworld_amd.build            # build if stale
+    python -m gridworld_amd.build --force
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the reference computes
+in IEEE binary64 with one rounding per operation; never add fast-math flags.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libigw_hip.so')
+SOURCES = ['igw_kernels.hip']
+HEADERS = ['igw_device.h', 'igw_trig.h', 'igw_trig_lut.h', os.path.join('..', '..', 'include', 'igw.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+         '-fno-fast-math', '-Wall', '-Wno-unused-variable']
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, extra_flags=(), verbose=False):
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

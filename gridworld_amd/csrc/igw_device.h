@@ -1,0 +1,446 @@
+// igw_device.h -- device-side building blocks of the gridworld step path (gfx950, wave64).
+//
+// Execution model: GS lanes of a wavefront (GS = 64, 32, 16 or 8; "group") own one env.
+// The serial double-precision physics chain is evaluated redundantly by every lane of the
+// group (no broadcast needed, the wave issues the instruction anyway); the lanes split
+//   * the coalesced int8 grid load/store HBM <-> LDS,
+//   * the 40 ray-march samples of hit_test,
+//   * the (target block, grid block) vote of maximal_intersection (whole wave, one env at a time).
+// All arithmetic is IEEE binary64 with one rounding per operation, in the reference's
+// operation order (compile with -ffp-contract=off, never fast-math).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/igw.h"
+#include "igw_trig.h"
+#include "igw_trig_lut.h"
+
+namespace igw {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+constexpr int CELLS = IGW_CELLS;
+constexpr int STRIDE = IGW_GRID_STRIDE;
+constexpr int CHUNKS = STRIDE / 16;  // 69 dwordx4 per grid row
+constexpr int LEVEL = 121;           // cells per y level
+// vote histogram: a non-empty target of x-extent wx admits 12 - wx <= 11 shifts dx (same for z), so
+// 4 rotations x 11 x 11 bins cover every admissible translation; 16-bit counters, two per word
+constexpr int HIST_BINS = 4 * 121;
+constexpr int HIST_WORDS = HIST_BINS / 2;  // 242
+constexpr int HIST_PAD = 256;
+
+// gridworld/utils.py:9-24 and core/world.py:9
+constexpr double WALKING_SPEED = 5.0;
+constexpr double FLYING_SPEED = 15.0;
+constexpr double GRAVITY = 20.0;
+constexpr double JUMP_SPEED = 0x1.bb67ae8584caap+2;  // sqrt(2 * 20.0 * 1.2) = 6.928203230275509
+constexpr double TERMINAL_VELOCITY = 50.0;
+constexpr double PAD = 0.25;
+constexpr double PI_OVER_180 = 0x1.1df46a2529d39p-6;   // pi / 180  (CPython math.radians)
+constexpr double D180_OVER_PI = 0x1.ca5dc1a63c1f8p+5;  // 180 / pi  (CPython math.degrees)
+
+struct alignas(16) AgentRec {  // layout documented in include/igw.h
+    double x, y, z, yaw, pitch, vy;
+    uint16_t step_no;
+    int16_t size, prev_size, max_int;
+    uint64_t inv_tis_active;  // bytes 0..5 inventory (int8), byte 6 time_int_steps, byte 7 active_block
+};
+static_assert(sizeof(AgentRec) == IGW_AGENT_BYTES, "agent record layout");
+
+struct alignas(16) TaskMeta {
+    double pose[5];
+    int16_t target_size, env_max_int;
+    int8_t bbox[16];
+    int8_t inv_init[6];
+    uint8_t has_start;
+    uint8_t pad[IGW_TASK_META_BYTES - 67];
+};
+static_assert(sizeof(TaskMeta) == IGW_TASK_META_BYTES, "task meta layout");
+
+struct KParams {
+    int32_t n_envs, select_and_place, size_reward, max_steps, autoreset;
+    double right_scale, wrong_scale;
+    int8_t* grid;
+    AgentRec* agent;
+    const int32_t* env_task;
+    const int8_t* task_target;
+    const int8_t* task_start;
+    const TaskMeta* task_meta;
+    float* agent_pos;
+    float* inventory;
+    float* compass;
+    float* reward;
+    uint8_t* done;
+    unsigned long long* stats;
+};
+
+// ---------------------------------------------------------------- lane groups
+
+template <int GS>
+struct Grp {
+    static constexpr int NG = WAVE / GS;
+    int lane;  // lane in wave
+    int gl;    // lane in group
+    int g;     // group in wave
+    __device__ Grp() {
+        lane = __lane_id();
+        gl = lane & (GS - 1);
+        g = lane / GS;
+    }
+    // ballot restricted to this group, bit i = lane i of the group
+    __device__ uint64_t ballot(bool p) const {
+        uint64_t m = __ballot(p);
+        if constexpr (GS == 64) return m;
+        else return (m >> (g * GS)) & ((1ull << GS) - 1ull);
+    }
+    // value held by lane `src` of this group (src uniform within the group)
+    __device__ int bcast(int v, int src) const {
+        if constexpr (GS == 64) return __builtin_amdgcn_readlane(v, src);
+        else return __shfl(v, src, GS);
+    }
+    __device__ int shfl_up1(int v) const { return __shfl_up(v, 1, GS); }
+};
+
+__device__ inline void wave_sync() {
+    // LDS traffic of one wave is ordered in hardware; this only stops the compiler
+    // from moving LDS accesses of different lanes across the point.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ inline int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- counter RNG
+// splitmix64 finaliser; actions = uniform Discrete(18) keyed by (seed, env, t)
+__host__ __device__ inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline int rng_action18(uint64_t seed, uint64_t env, uint64_t t) {
+    uint64_t h = splitmix64(seed ^ splitmix64(env * 0x100000001B3ull + t));
+    return (int)(((h >> 32) * 18ull) >> 32);
+}
+
+// ---------------------------------------------------------------- env registers
+
+struct Env {  // uniform across the lanes of a group
+    double x, y, z, yaw, pitch, vy;
+    int step_no, size, prev_size, max_int;
+    uint64_t inv;  // 6 x int8
+    int tis, active;
+};
+
+__device__ inline int inv_get(uint64_t inv, int i) { return (int)(int8_t)(inv >> (8 * i)); }
+__device__ inline uint64_t inv_add(uint64_t inv, int i, int d) {
+    int v = inv_get(inv, i) + d;
+    int sh = 8 * i;
+    return (inv & ~(0xffull << sh)) | ((uint64_t)(uint8_t)v << sh);
+}
+
+__device__ inline void env_load(Env& e, const AgentRec* rec) {
+    // every lane reads the same 64 B line (one request per wave)
+    const AgentRec r = *rec;
+    e.x = r.x; e.y = r.y; e.z = r.z; e.yaw = r.yaw; e.pitch = r.pitch; e.vy = r.vy;
+    e.step_no = r.step_no; e.size = r.size; e.prev_size = r.prev_size; e.max_int = r.max_int;
+    e.inv = r.inv_tis_active & 0x0000ffffffffffffull;
+    e.tis = (int)((r.inv_tis_active >> 48) & 0xff);
+    e.active = (int)(r.inv_tis_active >> 56);
+}
+__device__ inline void env_store(const Env& e, AgentRec* rec) {
+    AgentRec r;
+    r.x = e.x; r.y = e.y; r.z = e.z; r.yaw = e.yaw; r.pitch = e.pitch; r.vy = e.vy;
+    r.step_no = (uint16_t)e.step_no; r.size = (int16_t)e.size;
+    r.prev_size = (int16_t)e.prev_size; r.max_int = (int16_t)e.max_int;
+    r.inv_tis_active = e.inv | ((uint64_t)(e.tis & 0xff) << 48) | ((uint64_t)(e.active & 0xff) << 56);
+    *rec = r;
+}
+
+// ---------------------------------------------------------------- world queries
+
+// core/world.py:57-58
+__device__ inline bool build_zone_d(double x, double y, double z, double pad) {
+    return -5.0 - pad <= x && x <= 5.0 + pad && -5.0 - pad <= z && z <= 5.0 + pad && -1.0 - pad <= y &&
+           y < 8.0 + pad;
+}
+__device__ inline bool build_zone_i(int x, int y, int z) {
+    return x >= -5 && x <= 5 && z >= -5 && z <= 5 && y >= -1 && y < 8;
+}
+__device__ inline int cell_of(int x, int y, int z) { return (y + 1) * LEVEL + (x + 5) * 11 + (z + 5); }
+
+// `key in world` / `world[key]` answered from the dense grid in LDS plus the fixed ground plane
+// (World._initialize, core/world.py:60-71: y=-2, |x|,|z|<=18, WHITE(-1) over the build zone else GREY(0)).
+__device__ inline bool world_lookup(const int8_t* grid_s, int x, int y, int z, int& colour) {
+    if (y == -2) {
+        colour = (x >= -5 && x <= 5 && z >= -5 && z <= 5) ? -1 : 0;
+        return x >= -18 && x <= 18 && z >= -18 && z <= 18;
+    }
+    if (!build_zone_i(x, y, z)) return false;
+    colour = grid_s[cell_of(x, y, z)];
+    return colour != 0;
+}
+__device__ inline bool world_has(const int8_t* grid_s, int x, int y, int z) {
+    int c;
+    return world_lookup(grid_s, x, y, z, c);
+}
+
+// ---------------------------------------------------------------- trig front-end
+
+struct TrigCtx {
+    const double* lut;  // LDS copy of IGW_TRIG_LUT: {cos, sin} of radians(5k), k = IGW_LUT_K0..
+};
+
+// cos / sin of math.radians(deg).  Multiples of 5 degrees inside the table (all that discrete
+// walking can produce) come from the LUT; anything else from the build's own
+// double-precision sincos (igw_trig.h).
+__device__ inline void sincos_deg(const TrigCtx& t, double deg, double& s, double& c) {
+    int id = (int)deg;
+    if ((double)id == deg && id >= 5 * IGW_LUT_K0 && id <= 5 * (IGW_LUT_K0 + IGW_LUT_N - 1) && (id % 5) == 0) {
+        int k = id / 5 - IGW_LUT_K0;
+        c = t.lut[2 * k];
+        s = t.lut[2 * k + 1];
+    } else {
+        igw_sincos(deg * PI_OVER_180, &s, &c);
+    }
+}
+
+// ---------------------------------------------------------------- collide (core/world.py:264-310)
+
+__device__ inline void collide(Env& e, const int8_t* grid_s, double& px, double& py, double& pz) {
+    const int nx = (int)__builtin_rint(px), ny = (int)__builtin_rint(py), nz = (int)__builtin_rint(pz);
+    double d;
+    // face (0, 1, 0)
+    d = (py - (double)ny) * 1.0;
+    if (!(d < PAD)) {
+        if (world_has(grid_s, nx, ny + 1, nz) || world_has(grid_s, nx, ny - 1 + 1, nz)) {
+            py -= (d - PAD) * 1.0;
+            e.vy = 0.0;
+        }
+    }
+    // face (0, -1, 0)
+    d = (py - (double)ny) * -1.0;
+    if (!(d < PAD)) {
+        if (world_has(grid_s, nx, ny - 1, nz) || world_has(grid_s, nx, ny - 1 - 1, nz)) {
+            py -= (d - PAD) * -1.0;
+            e.vy = 0.0;
+        }
+    }
+    // face (-1, 0, 0)
+    d = (px - (double)nx) * -1.0;
+    if (!(d < PAD)) {
+        if (world_has(grid_s, nx - 1, ny, nz) || world_has(grid_s, nx - 1, ny - 1, nz)) px -= (d - PAD) * -1.0;
+    }
+    // face (1, 0, 0)
+    d = (px - (double)nx) * 1.0;
+    if (!(d < PAD)) {
+        if (world_has(grid_s, nx + 1, ny, nz) || world_has(grid_s, nx + 1, ny - 1, nz)) px -= (d - PAD) * 1.0;
+    }
+    // face (0, 0, 1)
+    d = (pz - (double)nz) * 1.0;
+    if (!(d < PAD)) {
+        if (world_has(grid_s, nx, ny, nz + 1) || world_has(grid_s, nx, ny - 1, nz + 1)) pz -= (d - PAD) * 1.0;
+    }
+    // face (0, 0, -1)
+    d = (pz - (double)nz) * -1.0;
+    if (!(d < PAD)) {
+        if (world_has(grid_s, nx, ny, nz - 1) || world_has(grid_s, nx, ny - 1, nz - 1)) pz -= (d - PAD) * -1.0;
+    }
+}
+
+// ---------------------------------------------------------------- hit_test (core/world.py:73-99)
+
+struct Hit {
+    bool hit, have_prev;
+    int bx, by, bz, colour;
+    int px, py, pz;
+};
+
+// Sample k is position + k sequential additions of vector/5 (the reference's recurrence, so the
+// rounding of every partial sum is reproduced); lane j of the group evaluates samples j, j+GS, ...
+// and a group ballot picks the first `key != previous and key in world`.
+template <int GS>
+__device__ inline Hit hit_test(const Grp<GS>& G, const int8_t* grid_s, double x, double y, double z,
+                               double vx, double vy, double vz) {
+    constexpr int SAMPLES = 40;  // max_distance 8 * m 5
+    constexpr int ROUNDS = (SAMPLES + GS - 1) / GS;
+    const double sx = vx / 5.0, sy = vy / 5.0, sz = vz / 5.0;
+    Hit h;
+    h.hit = false; h.have_prev = false;
+    h.bx = h.by = h.bz = h.colour = 0;
+    h.px = h.py = h.pz = 0;
+    int lkx = 0, lky = 0, lkz = 0;  // key of the last sample of the previous round
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int s = r * GS + G.gl;
+        int nadd = (r == 0) ? G.gl : GS;
+        if (GS == 64) nadd = min(nadd, SAMPLES - 1);
+        const int bound = (r == 0) ? min(GS - 1, SAMPLES - 1) : GS;
+        for (int i = 0; i < bound; i++) {
+            if (i < nadd) { x = x + sx; y = y + sy; z = z + sz; }
+        }
+        const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
+        int qx = G.shfl_up1(kx), qy = G.shfl_up1(ky), qz = G.shfl_up1(kz);
+        if (G.gl == 0) { qx = lkx; qy = lky; qz = lkz; }
+        const bool differs = (s == 0) || kx != qx || ky != qy || kz != qz;
+        int col = 0;
+        const bool inw = world_lookup(grid_s, kx, ky, kz, col);
+        const bool cand = !h.hit && s < SAMPLES && differs && inw;
+        const uint64_t m = G.ballot(cand);
+        if (m != 0 && !h.hit) {
+            const int first = __builtin_ctzll(m);
+            h.hit = true;
+            h.have_prev = !(r == 0 && first == 0);
+            h.bx = G.bcast(kx, first); h.by = G.bcast(ky, first); h.bz = G.bcast(kz, first);
+            h.colour = G.bcast(col, first);
+            h.px = G.bcast(qx, first); h.py = G.bcast(qy, first); h.pz = G.bcast(qz, first);
+        }
+        if (r + 1 < ROUNDS) {
+            lkx = G.bcast(kx, GS - 1); lky = G.bcast(ky, GS - 1); lkz = G.bcast(kz, GS - 1);
+        }
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------- maximal_intersection
+// (tasks/task.py:147-161 restated as a vote: every (target block, grid block) pair on the same
+// level with equal non-zero value votes for translation (tx - gx, tz - gz) of each rotation; the
+// answer is the best admissible bin.  Admissible set == bounding-box rule, tasks/task.py:62-72.)
+
+struct MiResult {
+    int max_int;
+    int arg_dx, arg_dz, arg_rot;
+};
+
+// Whole wave, one env.  grid_s: LDS grid of the env; start_g: global starting grid row or nullptr
+// (grid values are compared as grid - start); tgt_s: LDS copy of the target row (rotation 0);
+// hist: HIST_PAD words of LDS; bbox: 4 x (xmin, xmax, zmin, zmax) packed one int per rotation.
+template <bool ARGMAX>
+__device__ inline MiResult max_intersection_wave(const int8_t* grid_s, const int8_t* start_g,
+                                                 const int8_t* tgt_s, uint32_t* hist, const int* bbox4,
+                                                 int nrot) {
+    const int lane = __lane_id();
+    MiResult res;
+    res.max_int = 0;
+    res.arg_dx = res.arg_dz = res.arg_rot = 0;
+    // empty target (bbox xmin > xmax): every translation is admissible but nothing can match
+    if ((int8_t)(bbox4[0] & 0xff) > (int8_t)((bbox4[0] >> 8) & 0xff)) return res;
+    for (int w = lane; w < HIST_PAD; w += WAVE) hist[w] = 0;
+    wave_sync();
+    const int c0 = lane, c1 = lane + 64;
+    const bool v1 = c1 < LEVEL;
+    const int tx0 = c0 / 11, tz0 = c0 % 11;
+    const int tx1 = v1 ? c1 / 11 : 0, tz1 = v1 ? c1 % 11 : 0;
+    int bb[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        bb[r][0] = (int8_t)(bbox4[r] & 0xff);
+        bb[r][1] = (int8_t)((bbox4[r] >> 8) & 0xff);
+        bb[r][2] = (int8_t)((bbox4[r] >> 16) & 0xff);
+        bb[r][3] = (int8_t)((bbox4[r] >> 24) & 0xff);
+    }
+    auto vote = [&](int tx, int tz, int gx, int gz) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (r < nrot) {
+                // rotation r of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
+                const int rx = r == 0 ? tx : r == 1 ? tz : r == 2 ? 10 - tx : 10 - tz;
+                const int rz = r == 0 ? tz : r == 1 ? 10 - tx : r == 2 ? 10 - tz : tx;
+                const int dx = rx - gx, dz = rz - gz;
+                const int dxlo = bb[r][1] - 10, dzlo = bb[r][3] - 10;
+                if (dx >= dxlo && dx <= bb[r][0] && dz >= dzlo && dz <= bb[r][2]) {
+                    const int bin = r * 121 + (dx - dxlo) * 11 + (dz - dzlo);
+                    atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
+                }
+            }
+        }
+    };
+    for (int y = 0; y < IGW_GRID_Y; y++) {
+        const int base = y * LEVEL;
+        int g0 = grid_s[base + c0];
+        int g1 = v1 ? grid_s[base + c1] : 0;
+        if (start_g) {
+            g0 -= start_g[base + c0];
+            if (v1) g1 -= start_g[base + c1];
+        }
+        const int t0 = tgt_s[base + c0];
+        const int t1 = v1 ? tgt_s[base + c1] : 0;
+        uint64_t gm0 = __ballot(g0 != 0), gm1 = __ballot(g1 != 0);
+        const uint64_t tany = __ballot((t0 | t1) != 0);
+        if ((gm0 | gm1) == 0 || tany == 0) continue;
+        while (gm0) {
+            const int b = __builtin_ctzll(gm0);
+            gm0 &= gm0 - 1;
+            const int val = __builtin_amdgcn_readlane(g0, b);
+            const int gx = b / 11, gz = b % 11;
+            if (t0 == val) vote(tx0, tz0, gx, gz);
+            if (t1 == val) vote(tx1, tz1, gx, gz);
+        }
+        while (gm1) {
+            const int b = __builtin_ctzll(gm1);
+            gm1 &= gm1 - 1;
+            const int val = __builtin_amdgcn_readlane(g1, b);
+            const int c = b + 64;
+            const int gx = c / 11, gz = c % 11;
+            if (t0 == val) vote(tx0, tz0, gx, gz);
+            if (t1 == val) vote(tx1, tz1, gx, gz);
+        }
+    }
+    wave_sync();
+    int best = 0;
+    for (int w = lane; w < HIST_WORDS; w += WAVE) {
+        const uint32_t v = hist[w];
+        best = max(best, (int)max(v & 0xffff, v >> 16));
+    }
+    res.max_int = wave_max_i32(best);
+    if (ARGMAX) {
+        // argmax_intersection (tasks/task.py:121-136): first strict maximum in (rot, dx, dz) order
+        int first = 0x7fffffff;
+        if (res.max_int > 0) {
+            for (int w = lane; w < HIST_WORDS; w += WAVE) {
+                const uint32_t v = hist[w];
+                if ((int)(v >> 16) == res.max_int) first = min(first, 2 * w + 1);
+                if ((int)(v & 0xffff) == res.max_int) first = min(first, 2 * w);
+            }
+        }
+        first = wave_min_i32(first);
+        if (first != 0x7fffffff) {
+            const int r = first / 121, rem = first % 121;
+            res.arg_rot = r;
+            const int xmax = r == 0 ? bb[0][1] : r == 1 ? bb[1][1] : r == 2 ? bb[2][1] : bb[3][1];
+            const int zmax = r == 0 ? bb[0][3] : r == 1 ? bb[1][3] : r == 2 ? bb[2][3] : bb[3][3];
+            res.arg_dx = rem / 11 + (xmax - 10);
+            res.arg_dz = rem % 11 + (zmax - 10);
+        }
+    }
+    wave_sync();
+    return res;
+}
+
+// wave-wide copy of one 1104-byte row HBM -> LDS (69 aligned dwordx4)
+__device__ inline void row_to_lds_wave(int8_t* dst_s, const int8_t* src_g) {
+    const int lane = __lane_id();
+    const uint4* s = reinterpret_cast<const uint4*>(src_g);
+    uint4* d = reinterpret_cast<uint4*>(dst_s);
+    for (int c = lane; c < CHUNKS; c += WAVE) d[c] = s[c];
+}
+template <int GS>
+__device__ inline void row_to_lds_group(int gl, int8_t* dst_s, const int8_t* src_g) {
+    const uint4* s = reinterpret_cast<const uint4*>(src_g);
+    uint4* d = reinterpret_cast<uint4*>(dst_s);
+    for (int c = gl; c < CHUNKS; c += GS) d[c] = s[c];
+}
+
+}  // namespace igw

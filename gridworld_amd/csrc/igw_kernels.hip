@@ -1,0 +1,894 @@
+// igw_kernels.hip -- HIP kernels (gfx950) and the C ABI of include/igw.h.
+//
+// Reference semantics reproduced (file:line relative to iglu-contest/gridworld):
+//   World.step                gridworld/core/world.py:434-456
+//   movement / move_camera    gridworld/core/world.py:338-356
+//   place_or_remove_block     gridworld/core/world.py:312-332  (+ env.py:136-153 grid callbacks)
+//   update / _update          gridworld/core/world.py:203-262
+//   GridWorld.step tail       gridworld/env.py:276-303, SizeReward.step env.py:325-331
+//   Task.step_intersection    gridworld/tasks/task.py:103-119
+//   GridWorld.reset           gridworld/env.py:206-261
+//   Task.__init__             gridworld/tasks/task.py:9-72
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see gridworld_amd/build.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "igw_device.h"
+#include "igw_trig_lut.h"
+
+namespace igw {
+
+enum { MODE_WALK = 0, MODE_FLY = 1 };
+
+struct ActIn {
+    const int32_t* actions;
+    const float* movement;
+    const float* camera;
+    const int32_t* inventory;
+    const int32_t* placement;
+};
+
+struct StepOut {
+    double reward;
+    bool done;
+};
+
+struct TaskView {  // per-group view of the env's task row (uniform in the group)
+    int task;
+    int target_size, env_max_int;
+    bool has_start;
+};
+
+__device__ inline void stat_add(unsigned long long* stats, int which, unsigned long long v) {
+    if (stats) atomicAdd(&stats[(blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + which], v);
+}
+
+// GridWorld.reset (env.py:206-261) for one env, executed by its lane group.  `grid_g` is the env's
+// HBM row, `grid_s` its LDS copy (may be nullptr when the kernel ends right after).
+template <int GS>
+__device__ inline void reset_env(const Grp<GS>& G, const KParams& p, Env& e, const TaskMeta* meta,
+                                 const int8_t* start_row, bool has_start, int8_t* grid_g, int8_t* grid_s,
+                                 bool keep_size) {
+    if (!keep_size) e.size = 0;  // SizeReward.reset, env.py:321-323
+    e.step_no = 0;               // env.py:217
+    e.prev_size = 0;             // _synthetic_task.reset(): prev_grid_size = 0, max_int = 0 (task.py:74-86)
+    e.max_int = 0;
+    uint4* dg = reinterpret_cast<uint4*>(grid_g);
+    uint4* ds = reinterpret_cast<uint4*>(grid_s);
+    const uint4* src = reinterpret_cast<const uint4*>(start_row);
+    for (int c = G.gl; c < CHUNKS; c += GS) {  // env.py:234-238: world := starting grid
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (has_start) v = src[c];
+        dg[c] = v;
+        if (grid_s) ds[c] = v;
+    }
+    e.x = meta->pose[0]; e.y = meta->pose[1]; e.z = meta->pose[2];  // env.py:239-240
+    e.yaw = meta->pose[3]; e.pitch = meta->pose[4];
+    uint64_t inv = 0;  // env.py:243-246
+#pragma unroll
+    for (int i = 0; i < 6; i++) inv |= (uint64_t)(uint8_t)meta->inv_init[i] << (8 * i);
+    e.inv = inv;
+    // agent.dy, time_int_steps, active_block are NOT reset by the reference
+}
+
+// obs of reset(): agentPos zeros, compass 0 (env.py:247-254)
+__device__ inline void write_reset_obs(const KParams& p, int env, const Env& e) {
+    float* ap = p.agent_pos + 5 * (size_t)env;
+    ap[0] = 0.f; ap[1] = 0.f; ap[2] = 0.f; ap[3] = 0.f; ap[4] = 0.f;
+    float* iv = p.inventory + 6 * (size_t)env;
+#pragma unroll
+    for (int i = 0; i < 6; i++) iv[i] = (float)inv_get(e.inv, i);
+    p.compass[env] = 0.f;
+}
+
+// obs of step(): env.py:281-289
+__device__ inline void write_step_obs(const KParams& p, int env, const Env& e) {
+    float* ap = p.agent_pos + 5 * (size_t)env;
+    ap[0] = (float)e.x; ap[1] = (float)e.y; ap[2] = (float)e.z; ap[3] = (float)e.pitch; ap[4] = (float)e.yaw;
+    float* iv = p.inventory + 6 * (size_t)env;
+#pragma unroll
+    for (int i = 0; i < 6; i++) iv[i] = (float)inv_get(e.inv, i);
+    p.compass[env] = (float)(e.yaw - 180.0);
+}
+
+struct CellChange {
+    int idx;  // -1: grid unchanged this step
+    int old_val, new_val;
+};
+
+// World.step (core/world.py:434-456) after action parsing, for one env; every lane of the group runs
+// it with identical inputs, hit_test splits its samples over the lanes.
+template <int GS, int MODE>
+__device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env& e, int8_t* grid_s,
+                                        const TrigCtx& trig, double s0, double s1, double dy, int inventory,
+                                        double cam0, double cam1, bool remove, bool add) {
+    constexpr bool FLY = MODE == MODE_FLY;
+    CellChange ch;
+    ch.idx = -1; ch.old_val = 0; ch.new_val = 0;
+    if (p.select_and_place && inventory != 0) { add = true; remove = false; }  // :444-446
+    // movement, :344-356
+    if (dy != 0.0 && e.vy == 0.0) e.vy = JUMP_SPEED * dy;
+    if (FLY && dy == 0.0) e.vy = 0.0;
+    if (inventory >= 1 && inventory <= 6) e.active = inventory;
+    // move_camera, :338-342
+    e.yaw = e.yaw + cam0;
+    {
+        double y = e.pitch + cam1;
+        y = 90.0 < y ? 90.0 : y;
+        y = -90.0 > y ? -90.0 : y;
+        e.pitch = y;
+    }
+    // place_or_remove_block, :312-332
+    if (add != remove) {
+        double sp, cp, sy, cy;
+        sincos_deg(trig, e.pitch, sp, cp);       // m = cos(radians(y)); dy = sin(radians(y))
+        sincos_deg(trig, e.yaw - 90.0, sy, cy);  // dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
+        const double vx = cy * cp, vy = sp, vz = sy * cp;
+        const Hit h = hit_test<GS>(G, grid_s, e.x, e.y, e.z, vx, vy, vz);
+        if (add) {
+            if (h.hit && h.have_prev) {
+                if (inv_get(e.inv, e.active - 1) > 0 && build_zone_i(h.px, h.py, h.pz)) {
+                    const double x = e.x, z = e.z;
+                    const double y = e.y - 1.0 + PAD;  // y - (PLAYER_HEIGHT - 1) + Agent.PAD
+                    const double bx = (double)h.px - 0.5, by = (double)h.py, bz = (double)h.pz - 0.5;
+                    const bool overlap = bx <= x && x <= bx + 1.0 && bz <= z && z <= bz + 1.0 &&
+                                         ((by <= y && y <= by + 1.0) || (by <= (y + 1.0) && (y + 1.0) <= by + 1.0));
+                    if (!overlap) {
+                        ch.idx = cell_of(h.px, h.py, h.pz);
+                        ch.old_val = 0;  // `previous` is never occupied
+                        ch.new_val = e.active;
+                        e.inv = inv_add(e.inv, e.active - 1, -1);
+                    }
+                }
+            }
+        }
+        if (remove && h.hit) {
+            const int texture = h.colour;
+            if (texture != 0 && texture != -1) {  // GREY / WHITE ground cannot be broken
+                ch.idx = cell_of(h.bx, h.by, h.bz);
+                ch.old_val = texture;
+                ch.new_val = 0;
+                if (texture >= 1 && texture <= 6) e.inv = inv_add(e.inv, texture - 1, 1);
+            }
+        }
+        if (ch.idx >= 0) {
+            wave_sync();
+            if (G.gl == 0) grid_s[ch.idx] = (int8_t)ch.new_val;
+            wave_sync();
+        }
+    }
+    // update(dt = 1/20), :203-220
+    {
+        const int m = e.tis;
+        const double dt = m == 2 ? 0.05 / 2 : m == 4 ? 0.05 / 4 : m == 8 ? 0.05 / 8 : 0.05 / 12;
+        // get_motion_vector, :163-201 (rotation and strafe are constant over the sub-steps)
+        double mvx = 0.0, mvy = 0.0, mvz = 0.0;
+        if (s0 != 0.0 || s1 != 0.0) {
+            double strafe_deg;
+            if (!FLY && s1 == 0.0) strafe_deg = s0 < 0.0 ? -90.0 : 90.0;       // degrees(atan2(-+1, 0))
+            else if (!FLY && s0 == 0.0) strafe_deg = s1 < 0.0 ? 180.0 : 0.0;   // degrees(atan2(0, -+1))
+            else strafe_deg = igw_atan2(s0, s1) * D180_OVER_PI;
+            double sx, cx;
+            sincos_deg(trig, e.yaw + strafe_deg, sx, cx);
+            if (FLY) {
+                double sp, cp;
+                sincos_deg(trig, e.pitch, sp, cp);
+                double mm = cp;
+                mvy = sp;
+                if (s1 != 0.0) { mvy = 0.0; mm = 1.0; }
+                if (s0 > 0.0) mvy *= -1.0;
+                mvx = cx * mm;
+                mvz = sx * mm;
+            } else {
+                mvy = 0.0;
+                mvx = cx;
+                mvz = sx;
+            }
+        }
+        for (int i = 0; i < m; i++) {  // _update, :222-262
+            const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
+            const double d = dt * speed;
+            const double ddx = mvx * d, ddz = mvz * d;
+            double ddy = mvy * d;
+            if (!FLY) {
+                e.vy -= dt * GRAVITY;
+                if (e.vy < -14.0) e.tis = 12;
+                else if (e.vy < -10.0) e.tis = 8;
+                else if (e.vy < -5.0) e.tis = 4;
+                else e.tis = 2;
+                e.vy = e.vy > -TERMINAL_VELOCITY ? e.vy : -TERMINAL_VELOCITY;
+            }
+            ddy += e.vy * dt;
+            double cx = e.x + ddx, cy = e.y + ddy, cz = e.z + ddz;
+            if (build_zone_d(cx, cy, cz, 2.0)) {
+                collide(e, grid_s, cx, cy, cz);
+                e.x = cx; e.y = cy; e.z = cz;
+            } else if (!FLY) {
+                cx = e.x; cz = e.z;
+                collide(e, grid_s, cx, cy, cz);
+                e.x = cx; e.y = cy; e.z = cz;
+            }
+        }
+        if (FLY) e.vy = 0.0;
+    }
+    // yaw wrap with strict comparisons (0 and 360 both survive), :451-456
+    while (e.yaw > 360.0) e.yaw -= 360.0;
+    while (e.yaw < 0.0) e.yaw += 360.0;
+    return ch;
+}
+
+// parse_walking_discrete_action (core/world.py:360-394) + World.step
+template <int GS>
+__device__ inline CellChange step_walking_action(const Grp<GS>& G, const KParams& p, Env& e, int8_t* grid_s,
+                                                 const TrigCtx& trig, int action) {
+    double s0 = 0.0, s1 = 0.0, dy = 0.0, cam0 = 0.0, cam1 = 0.0;
+    int inventory = 0;
+    bool remove = false, add = false;
+    if (action == 1) s0 = -1.0;
+    else if (action == 2) s0 = 1.0;
+    else if (action == 3) s1 = -1.0;
+    else if (action == 4) s1 = 1.0;
+    else if (action == 5) dy = 1.0;
+    else if (action >= 6 && action <= 11) inventory = action - 5;
+    else if (action == 12) cam0 = -5.0;
+    else if (action == 13) cam0 = 5.0;
+    else if (action == 14) cam1 = -5.0;
+    else if (action == 15) cam1 = 5.0;
+    else if (action == 16) remove = true;
+    else if (action == 17) add = true;
+    return world_step<GS, MODE_WALK>(G, p, e, grid_s, trig, s0, s1, dy, inventory, cam0, cam1, remove, add);
+}
+
+// Task.step_intersection (tasks/task.py:103-119) part 1: block-count delta of the synthetic grid
+// (grid - start).  Only one cell can change per step, so the count is updated incrementally.
+__device__ inline int syn_size_delta(const CellChange& ch, int start_val) {
+    if (ch.idx < 0) return 0;
+    return ((ch.new_val - start_val) != 0 ? 1 : 0) - ((ch.old_val - start_val) != 0 ? 1 : 0);
+}
+
+// part 2 + GridWorld.step tail (env.py:290-296) + SizeReward.step (env.py:325-331)
+__device__ inline StepOut finish_step(const KParams& p, Env& e, const TaskView& tv, int size_new, int mi) {
+    const int wrong = e.prev_size - size_new;
+    bool done = mi == tv.target_size;
+    e.prev_size = size_new;
+    const int right = mi - e.max_int;
+    e.max_int = mi;
+    done = done || (e.step_no == p.max_steps);
+    double reward;
+    if (right == 0) reward = (double)wrong * p.wrong_scale;
+    else reward = (double)right * p.right_scale;
+    if (p.size_reward) {
+        const int mx = max(tv.env_max_int, e.size);
+        reward = (double)(mx - e.size);
+        e.size = mx;
+    }
+    StepOut o;
+    o.reward = reward;
+    o.done = done;
+    return o;
+}
+
+template <int GS>
+struct BlockShared {
+    static constexpr int EPB = BLOCK / GS;  // envs per block
+    double lut[IGW_LUT_N * 2];
+    alignas(16) int8_t grid[EPB][STRIDE];
+    alignas(16) int8_t tgt[WAVES_PER_BLOCK][STRIDE];
+    uint32_t hist[WAVES_PER_BLOCK][HIST_PAD];
+};
+
+__constant__ double IGW_TRIG_LUT_DEV[IGW_LUT_N * 2];
+
+__device__ inline void load_lut(double* lut_s) {
+    for (int i = threadIdx.x; i < IGW_LUT_N * 2; i += BLOCK) lut_s[i] = IGW_TRIG_LUT_DEV[i];
+    __syncthreads();
+}
+
+// max_intersection for every group of this wave that asked for it, one env at a time with all 64 lanes
+template <int GS>
+__device__ inline int resolve_max_intersection(const Grp<GS>& G, const KParams& p, BlockShared<GS>& sh,
+                                               bool need, int slot, int task, bool has_start, int mi_cached) {
+    const int wave = threadIdx.x / WAVE;
+    uint64_t needm = __ballot(need);
+    int mi = mi_cached;
+    while (needm) {
+        const int l = __builtin_ctzll(needm);
+        const int gsel = l / GS;
+        if constexpr (GS == 64) needm = 0;
+        else needm &= ~(((1ull << GS) - 1ull) << (gsel * GS));
+        const int t_task = __builtin_amdgcn_readlane(task, l);
+        const int t_slot = __builtin_amdgcn_readlane(slot, l);
+        const int t_hs = __builtin_amdgcn_readlane((int)has_start, l);
+        const int* bbp = reinterpret_cast<const int*>(p.task_meta[t_task].bbox);
+        int bbox4[4] = {bbp[0], bbp[1], bbp[2], bbp[3]};
+        wave_sync();
+        row_to_lds_wave(sh.tgt[wave], p.task_target + (size_t)t_task * STRIDE);
+        wave_sync();
+        const MiResult r = max_intersection_wave<false>(
+            sh.grid[t_slot], t_hs ? p.task_start + (size_t)t_task * STRIDE : nullptr, sh.tgt[wave],
+            sh.hist[wave], bbox4, 4);
+        if (G.g == gsel) mi = r.max_int;
+    }
+    return mi;
+}
+
+template <int GS, int MODE>
+__global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
+    __shared__ BlockShared<GS> sh;
+    const Grp<GS> G;
+    TrigCtx trig;
+    trig.lut = sh.lut;
+    load_lut(sh.lut);
+    const int slot = threadIdx.x / GS;
+    const int env = blockIdx.x * BlockShared<GS>::EPB + slot;
+    const bool active = env < p.n_envs;
+    if (GS == 64 && !active) return;
+    Env e = {};
+    TaskView tv = {};
+    const TaskMeta* meta = nullptr;
+    int8_t* grid_s = sh.grid[slot];
+    int8_t* grid_g = nullptr;
+    CellChange ch;
+    ch.idx = -1; ch.old_val = ch.new_val = 0;
+    int size_new = 0;
+    bool need = false;
+    if (active) {
+        grid_g = p.grid + (size_t)env * STRIDE;
+        row_to_lds_group<GS>(G.gl, grid_s, grid_g);
+        tv.task = p.env_task[env];
+        meta = p.task_meta + tv.task;
+        tv.target_size = meta->target_size;
+        tv.env_max_int = meta->env_max_int;
+        tv.has_start = meta->has_start != 0;
+        env_load(e, p.agent + env);
+        wave_sync();
+        e.step_no = min(e.step_no + 1, 65535);  // env.py:276
+        if (MODE == MODE_WALK) {
+            ch = step_walking_action<GS>(G, p, e, grid_s, trig, a.actions[env]);
+        } else {  // parse_flying_action, core/world.py:416-432
+            const float* mv = a.movement + 3 * (size_t)env;
+            const float* cam = a.camera + 2 * (size_t)env;
+            const int placement = a.placement[env];
+            ch = world_step<GS, MODE_FLY>(G, p, e, grid_s, trig, (double)mv[0], (double)mv[1], (double)mv[2],
+                                          a.inventory[env], (double)cam[0], (double)cam[1], placement == 2,
+                                          placement == 1);
+        }
+        int start_val = 0;
+        if (ch.idx >= 0 && tv.has_start) start_val = p.task_start[(size_t)tv.task * STRIDE + ch.idx];
+        size_new = e.prev_size + syn_size_delta(ch, start_val);
+        need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
+    }
+    const int mi = resolve_max_intersection<GS>(G, p, sh, need, slot, tv.task, tv.has_start, e.max_int);
+    if (!active) return;
+    const StepOut o = finish_step(p, e, tv, size_new, mi);
+    const bool do_reset = o.done && p.autoreset;
+    if (do_reset) {
+        reset_env<GS>(G, p, e, meta, p.task_start + (size_t)tv.task * STRIDE, tv.has_start, grid_g, nullptr,
+                      false);
+    }
+    if (G.gl == 0) {
+        if (ch.idx >= 0 && !do_reset) grid_g[ch.idx] = (int8_t)ch.new_val;
+        p.reward[env] = (float)o.reward;
+        p.done[env] = o.done ? 1 : 0;
+        if (do_reset) write_reset_obs(p, env, e);
+        else write_step_obs(p, env, e);
+        env_store(e, p.agent + env);
+        if (need) stat_add(p.stats, IGW_STAT_CHANGED, 1);
+        if (do_reset) stat_add(p.stats, IGW_STAT_RESETS, 1);
+    }
+}
+
+// T fused walking steps, state resident in registers + LDS, counter-RNG actions, auto-reset on done
+template <int GS>
+__global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, unsigned long long seed,
+                                                        long long t0, long long env_offset) {
+    __shared__ BlockShared<GS> sh;
+    const Grp<GS> G;
+    TrigCtx trig;
+    trig.lut = sh.lut;
+    load_lut(sh.lut);
+    const int slot = threadIdx.x / GS;
+    const int env = blockIdx.x * BlockShared<GS>::EPB + slot;
+    const bool active = env < p.n_envs;
+    if (GS == 64 && !active) return;
+    Env e = {};
+    TaskView tv = {};
+    const TaskMeta* meta = nullptr;
+    int8_t* grid_s = sh.grid[slot];
+    int8_t* grid_g = nullptr;
+    if (active) {
+        grid_g = p.grid + (size_t)env * STRIDE;
+        row_to_lds_group<GS>(G.gl, grid_s, grid_g);
+        tv.task = p.env_task[env];
+        meta = p.task_meta + tv.task;
+        tv.target_size = meta->target_size;
+        tv.env_max_int = meta->env_max_int;
+        tv.has_start = meta->has_start != 0;
+        env_load(e, p.agent + env);
+    }
+    wave_sync();
+    unsigned long long n_changed = 0, n_resets = 0;
+    StepOut o;
+    o.reward = 0.0; o.done = false;
+    bool last_reset = false;
+    for (long long t = 0; t < T; t++) {
+        CellChange ch;
+        ch.idx = -1; ch.old_val = ch.new_val = 0;
+        int size_new = 0;
+        bool need = false;
+        if (active) {
+            e.step_no = min(e.step_no + 1, 65535);
+            const int action = rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
+            ch = step_walking_action<GS>(G, p, e, grid_s, trig, action);
+            int start_val = 0;
+            if (ch.idx >= 0 && tv.has_start) start_val = p.task_start[(size_t)tv.task * STRIDE + ch.idx];
+            size_new = e.prev_size + syn_size_delta(ch, start_val);
+            need = size_new != e.prev_size;
+        }
+        const int mi = resolve_max_intersection<GS>(G, p, sh, need, slot, tv.task, tv.has_start, e.max_int);
+        if (active) {
+            o = finish_step(p, e, tv, size_new, mi);
+            n_changed += need;
+            last_reset = o.done;
+            if (o.done) {
+                wave_sync();
+                reset_env<GS>(G, p, e, meta, p.task_start + (size_t)tv.task * STRIDE, tv.has_start, grid_g,
+                              grid_s, false);
+                wave_sync();
+                n_resets++;
+            }
+        }
+    }
+    if (!active) return;
+    wave_sync();
+    {  // grid row back to HBM
+        const uint4* s = reinterpret_cast<const uint4*>(grid_s);
+        uint4* d = reinterpret_cast<uint4*>(grid_g);
+        for (int c = G.gl; c < CHUNKS; c += GS) d[c] = s[c];
+    }
+    if (G.gl == 0) {
+        p.reward[env] = (float)o.reward;
+        p.done[env] = o.done ? 1 : 0;
+        if (last_reset) write_reset_obs(p, env, e);
+        else write_step_obs(p, env, e);
+        env_store(e, p.agent + env);
+        if (n_changed) stat_add(p.stats, IGW_STAT_CHANGED, n_changed);
+        if (n_resets) stat_add(p.stats, IGW_STAT_RESETS, n_resets);
+        stat_add(p.stats, IGW_STAT_STEPS, (unsigned long long)T);
+    }
+}
+
+template <int GS>
+__global__ __launch_bounds__(BLOCK) void reset_kernel(KParams p, const uint8_t* mask, int keep_size) {
+    const Grp<GS> G;
+    const int slot = threadIdx.x / GS;
+    const int env = blockIdx.x * (BLOCK / GS) + slot;
+    if (env >= p.n_envs) return;
+    if (mask && !mask[env]) return;
+    Env e;
+    env_load(e, p.agent + env);
+    const int task = p.env_task[env];
+    const TaskMeta* meta = p.task_meta + task;
+    reset_env<GS>(G, p, e, meta, p.task_start + (size_t)task * STRIDE, meta->has_start != 0,
+                  p.grid + (size_t)env * STRIDE, nullptr, keep_size != 0);
+    if (G.gl == 0) {
+        write_reset_obs(p, env, e);
+        p.reward[env] = 0.f;
+        p.done[env] = 0;
+        env_store(e, p.agent + env);
+    }
+}
+
+__global__ void fill_actions_kernel(int32_t* actions, long long n_envs, long long n_steps, long long t0,
+                                    unsigned long long seed, long long env_offset) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_envs * n_steps) return;
+    const long long t = i / n_envs, env = i % n_envs;
+    actions[i] = rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
+}
+
+// ---------------------------------------------------------------- Task.__init__ on device
+
+struct BBox {
+    int xmin, xmax, zmin, zmax;
+};
+
+// bounding box of the non-zero cells of an LDS row (wave-wide); empty -> (10, 0, 10, 0)
+__device__ inline BBox row_bbox(const int8_t* row_s, int& nnz) {
+    const int lane = __lane_id();
+    int xmin = 10, xmax = 0, zmin = 10, zmax = 0, cnt = 0;
+    for (int c = lane; c < CELLS; c += WAVE) {
+        if (row_s[c] != 0) {
+            const int r = c % LEVEL, x = r / 11, z = r % 11;
+            xmin = min(xmin, x); xmax = max(xmax, x);
+            zmin = min(zmin, z); zmax = max(zmax, z);
+            cnt++;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    nnz = cnt;
+    BBox b;
+    b.xmin = wave_min_i32(xmin); b.xmax = wave_max_i32(xmax);
+    b.zmin = wave_min_i32(zmin); b.zmax = wave_max_i32(zmax);
+    if (cnt == 0) { b.xmin = 10; b.xmax = 0; b.zmin = 10; b.zmax = 0; }
+    return b;
+}
+
+__device__ inline int pack_bbox(int xmin, int xmax, int zmin, int zmax) {
+    return (xmin & 0xff) | ((xmax & 0xff) << 8) | ((zmin & 0xff) << 16) | ((zmax & 0xff) << 24);
+}
+// bboxes of the 4 rotations (x,z) -> (z, 10-x) (tasks/task.py:52-53) of a box; admissible translations
+// of rotation r are dx in [xmax-10, xmin], dz in [zmax-10, zmin] (tasks/task.py:62-72 as a bbox rule)
+__device__ inline void rot_bboxes(const BBox& b, bool empty, int* out4) {
+    if (empty) {
+        out4[0] = out4[1] = out4[2] = out4[3] = pack_bbox(10, 0, 10, 0);
+        return;
+    }
+    out4[0] = pack_bbox(b.xmin, b.xmax, b.zmin, b.zmax);
+    out4[1] = pack_bbox(b.zmin, b.zmax, 10 - b.xmax, 10 - b.xmin);
+    out4[2] = pack_bbox(10 - b.xmax, 10 - b.xmin, 10 - b.zmax, 10 - b.zmin);
+    out4[3] = pack_bbox(10 - b.zmax, 10 - b.zmin, b.xmin, b.xmax);
+}
+
+struct PrepShared {
+    alignas(16) int8_t a[WAVES_PER_BLOCK][STRIDE];  // target / synthetic target
+    alignas(16) int8_t b[WAVES_PER_BLOCK][STRIDE];  // starting grid / evaluation grid
+    alignas(16) int8_t c[WAVES_PER_BLOCK][STRIDE];  // full grid
+    uint32_t hist[WAVES_PER_BLOCK][HIST_PAD];
+};
+
+__device__ inline void zero_row_lds_wave(int8_t* dst_s) {
+    uint4* d = reinterpret_cast<uint4*>(dst_s);
+    for (int c = __lane_id(); c < CHUNKS; c += WAVE) d[c] = make_uint4(0, 0, 0, 0);
+}
+
+// one wavefront per task row
+__global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int first, int n,
+                                                              const int8_t* user_target, const int8_t* start,
+                                                              const int8_t* full_grid, const uint8_t* invariant,
+                                                              const double* init_pose) {
+    __shared__ PrepShared sh;
+    const int wave = threadIdx.x / WAVE, lane = __lane_id();
+    const int i = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (i >= n) return;
+    const int task = first + i;
+    int8_t* T = sh.a[wave];
+    int8_t* S = sh.b[wave];
+    int8_t* F = sh.c[wave];
+    row_to_lds_wave(T, user_target + (size_t)i * STRIDE);
+    if (start) row_to_lds_wave(S, start + (size_t)i * STRIDE);
+    else zero_row_lds_wave(S);
+    if (full_grid) row_to_lds_wave(F, full_grid + (size_t)i * STRIDE);
+    wave_sync();
+    // GridWorld.max_int at reset = user task on the starting grid (env.py:241); the user task's
+    // admissible set comes from full_grid when given (task.py:63-66), or is [(0,0)] if not invariant
+    const bool inv = invariant ? invariant[i] != 0 : true;
+    int nnz_u = 0, nnz_s = 0;
+    const BBox bu = row_bbox(full_grid ? F : T, nnz_u);
+    int bb_user[4];
+    if (inv) rot_bboxes(bu, nnz_u == 0, bb_user);
+    else bb_user[0] = bb_user[1] = bb_user[2] = bb_user[3] = pack_bbox(0, 10, 0, 10);  // only (0, 0)
+    const MiResult r = max_intersection_wave<false>(S, nullptr, T, sh.hist[wave], bb_user, inv ? 4 : 1);
+    // starting grid -> table, inventory at reset (env.py:243-246)
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = lane; c < CELLS; c += WAVE) {
+        const int v = S[c];
+        nnz_s += v != 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) cnt[k] += v == k + 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nnz_s += __shfl_xor(nnz_s, o, 64);
+#pragma unroll
+        for (int k = 0; k < 6; k++) cnt[k] += __shfl_xor(cnt[k], o, 64);
+    }
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(S);
+        uint4* d = reinterpret_cast<uint4*>(const_cast<int8_t*>(p.task_start) + (size_t)task * STRIDE);
+        for (int c = lane; c < CHUNKS; c += WAVE) d[c] = s[c];
+    }
+    // synthetic target = target - starting grid (env.py:227-231), always invariant, no full grid
+    wave_sync();
+    for (int c = lane; c < STRIDE; c += WAVE) T[c] = (int8_t)(c < CELLS ? T[c] - S[c] : 0);
+    wave_sync();
+    int nnz_t = 0;
+    const BBox bs = row_bbox(T, nnz_t);
+    int bb_syn[4];
+    rot_bboxes(bs, nnz_t == 0, bb_syn);
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(T);
+        uint4* d = reinterpret_cast<uint4*>(const_cast<int8_t*>(p.task_target) + (size_t)task * STRIDE);
+        for (int c = lane; c < CHUNKS; c += WAVE) d[c] = s[c];
+    }
+    if (lane == 0) {
+        TaskMeta m;
+        memset(&m, 0, sizeof(m));
+        for (int k = 0; k < 5; k++) m.pose[k] = init_pose ? init_pose[5 * (size_t)i + k] : 0.0;
+        m.target_size = (int16_t)nnz_t;
+        m.env_max_int = (int16_t)r.max_int;
+        for (int k = 0; k < 4; k++) {
+            m.bbox[4 * k + 0] = (int8_t)(bb_syn[k] & 0xff);
+            m.bbox[4 * k + 1] = (int8_t)((bb_syn[k] >> 8) & 0xff);
+            m.bbox[4 * k + 2] = (int8_t)((bb_syn[k] >> 16) & 0xff);
+            m.bbox[4 * k + 3] = (int8_t)((bb_syn[k] >> 24) & 0xff);
+        }
+        for (int k = 0; k < 6; k++) m.inv_init[k] = (int8_t)(20 - cnt[k]);
+        m.has_start = nnz_s != 0;
+        const_cast<TaskMeta*>(p.task_meta)[task] = m;
+    }
+}
+
+// stateless Task(target, full_grid, invariant) evaluated on grid (tasks/task.py:121-161)
+__global__ __launch_bounds__(BLOCK) void task_eval_kernel(int n, const int8_t* target, const int8_t* grid,
+                                                          const int8_t* full_grid, const uint8_t* invariant,
+                                                          int32_t* max_int, int32_t* argmax,
+                                                          int32_t* target_size) {
+    __shared__ PrepShared sh;
+    const int wave = threadIdx.x / WAVE, lane = __lane_id();
+    const int i = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (i >= n) return;
+    int8_t* T = sh.a[wave];
+    int8_t* Gd = sh.b[wave];
+    int8_t* F = sh.c[wave];
+    row_to_lds_wave(T, target + (size_t)i * STRIDE);
+    row_to_lds_wave(Gd, grid + (size_t)i * STRIDE);
+    if (full_grid) row_to_lds_wave(F, full_grid + (size_t)i * STRIDE);
+    wave_sync();
+    const bool inv = invariant ? invariant[i] != 0 : true;
+    int nnz_t = 0, nnz_f = 0;
+    const BBox bt = row_bbox(T, nnz_t);
+    BBox bu = bt;
+    int nnz_u = nnz_t;
+    if (full_grid) { bu = row_bbox(F, nnz_f); nnz_u = nnz_f; }
+    int bb[4];
+    if (inv) rot_bboxes(bu, nnz_u == 0, bb);
+    else bb[0] = bb[1] = bb[2] = bb[3] = pack_bbox(0, 10, 0, 10);
+    const MiResult r = max_intersection_wave<true>(Gd, nullptr, T, sh.hist[wave], bb, inv ? 4 : 1);
+    if (lane == 0) {
+        if (max_int) max_int[i] = r.max_int;
+        if (argmax) { argmax[3 * i] = r.arg_dx; argmax[3 * i + 1] = r.arg_dz; argmax[3 * i + 2] = r.arg_rot; }
+        if (target_size) target_size[i] = nnz_t;
+    }
+}
+
+}  // namespace igw
+
+// ================================================================= C ABI
+
+using namespace igw;
+
+struct igw_ctx {
+    igw_config cfg;
+    KParams kp;
+    bool bound;
+    int gs;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) return fail(IGW_ERR_HIP, #expr ": %s", hipGetErrorString(_e)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+static hipError_t upload_lut() {
+    static thread_local int done_for = -1;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (done_for == dev) return hipSuccess;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(IGW_TRIG_LUT_DEV), IGW_TRIG_LUT_HOST, sizeof(IGW_TRIG_LUT_HOST));
+    if (e == hipSuccess) done_for = dev;
+    return e;
+}
+
+extern "C" {
+
+int igw_version(void) { return IGW_VERSION; }
+const char* igw_last_error(void) { return g_err; }
+
+int igw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int igw_create(const igw_config* cfg, igw_ctx** out) {
+    if (!cfg || !out) return fail(IGW_ERR_INVALID, "igw_create: null argument");
+    *out = nullptr;
+    if (cfg->num_envs < 1 || cfg->num_tasks < 1) return fail(IGW_ERR_INVALID, "igw_create: num_envs / num_tasks must be >= 1");
+    if (cfg->max_steps < 1 || cfg->max_steps > 65534) return fail(IGW_ERR_INVALID, "igw_create: max_steps must be in 1..65534");
+    if (cfg->action_space != IGW_WALKING_DISCRETE && cfg->action_space != IGW_FLYING)
+        return fail(IGW_ERR_INVALID, "igw_create: unknown action_space");
+    int gs = cfg->lanes_per_env ? cfg->lanes_per_env : 64;
+    if (gs != 64 && gs != 32 && gs != 16 && gs != 8) return fail(IGW_ERR_INVALID, "igw_create: lanes_per_env must be 0, 64, 32, 16 or 8");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return fail(IGW_ERR_NO_DEVICE, "igw_create: no HIP device available (the HIP path has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= n) return fail(IGW_ERR_INVALID, "igw_create: device ordinal out of range");
+    igw_ctx* c = new (std::nothrow) igw_ctx();
+    if (!c) return fail(IGW_ERR_INVALID, "igw_create: out of memory");
+    c->cfg = *cfg;
+    c->bound = false;
+    c->gs = gs;
+    memset(&c->kp, 0, sizeof(c->kp));
+    c->kp.n_envs = cfg->num_envs;
+    c->kp.select_and_place = cfg->select_and_place;
+    c->kp.size_reward = cfg->size_reward;
+    c->kp.max_steps = cfg->max_steps;
+    c->kp.autoreset = cfg->autoreset;
+    c->kp.right_scale = cfg->right_placement_scale;
+    c->kp.wrong_scale = cfg->wrong_placement_scale;
+    {
+        DeviceGuard g(cfg->device);
+        if (!g.ok) { delete c; return fail(IGW_ERR_HIP, "igw_create: hipSetDevice failed"); }
+        hipError_t e = upload_lut();
+        if (e != hipSuccess) { delete c; return fail(IGW_ERR_HIP, "igw_create: LUT upload: %s", hipGetErrorString(e)); }
+    }
+    *out = c;
+    return IGW_OK;
+}
+
+int igw_destroy(igw_ctx* ctx) {
+    delete ctx;
+    return IGW_OK;
+}
+
+int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
+    if (!ctx || !b) return fail(IGW_ERR_INVALID, "igw_bind_buffers: null argument");
+    if (!b->grid || !b->agent || !b->env_task || !b->task_target || !b->task_start || !b->task_meta ||
+        !b->agent_pos || !b->inventory || !b->compass || !b->reward || !b->done)
+        return fail(IGW_ERR_INVALID, "igw_bind_buffers: a required buffer is null");
+    if (((uintptr_t)b->grid | (uintptr_t)b->agent | (uintptr_t)b->task_target | (uintptr_t)b->task_start |
+         (uintptr_t)b->task_meta) & 15)
+        return fail(IGW_ERR_INVALID, "igw_bind_buffers: grid / agent / task buffers must be 16-byte aligned");
+    KParams& k = ctx->kp;
+    k.grid = b->grid;
+    k.agent = reinterpret_cast<AgentRec*>(b->agent);
+    k.env_task = b->env_task;
+    k.task_target = b->task_target;
+    k.task_start = b->task_start;
+    k.task_meta = reinterpret_cast<const TaskMeta*>(b->task_meta);
+    k.agent_pos = b->agent_pos;
+    k.inventory = b->inventory;
+    k.compass = b->compass;
+    k.reward = b->reward;
+    k.done = b->done;
+    k.stats = reinterpret_cast<unsigned long long*>(b->stats);
+    ctx->bound = true;
+    return IGW_OK;
+}
+
+#define CHECK_CTX(name)                                                        \
+    if (!ctx) return fail(IGW_ERR_INVALID, name ": null context");             \
+    if (!ctx->bound) return fail(IGW_ERR_UNBOUND, name ": buffers not bound"); \
+    DeviceGuard guard(ctx->cfg.device);                                        \
+    if (!guard.ok) return fail(IGW_ERR_HIP, name ": hipSetDevice failed");     \
+    HIP_TRY(upload_lut())
+
+#define DISPATCH_GS(gs, CALL)          \
+    switch (gs) {                      \
+        case 64: { constexpr int GS = 64; CALL; } break; \
+        case 32: { constexpr int GS = 32; CALL; } break; \
+        case 16: { constexpr int GS = 16; CALL; } break; \
+        default: { constexpr int GS = 8; CALL; } break;  \
+    }
+
+static inline int env_blocks(const igw_ctx* ctx) {
+    const int epb = BLOCK / ctx->gs;
+    return (ctx->cfg.num_envs + epb - 1) / epb;
+}
+
+int igw_prepare_tasks(igw_ctx* ctx, int32_t first, int32_t n, const int8_t* user_target, const int8_t* start,
+                      const int8_t* full_grid, const uint8_t* invariant, const double* init_pose, void* stream) {
+    CHECK_CTX("igw_prepare_tasks");
+    if (n < 0 || first < 0 || first + n > ctx->cfg.num_tasks) return fail(IGW_ERR_INVALID, "igw_prepare_tasks: task range outside the table");
+    if (!user_target) return fail(IGW_ERR_INVALID, "igw_prepare_tasks: user_target is null");
+    if (n == 0) return IGW_OK;
+    const int blocks = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(prepare_tasks_kernel, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, ctx->kp, first, n,
+                       user_target, start, full_grid, invariant, init_pose);
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_reset(igw_ctx* ctx, const uint8_t* mask, int32_t flags, void* stream) {
+    CHECK_CTX("igw_reset");
+    const int keep = (flags & IGW_RESET_KEEP_SIZE) ? 1 : 0;
+    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(reset_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
+                                            (hipStream_t)stream, ctx->kp, mask, keep));
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_step_walking(igw_ctx* ctx, const int32_t* actions, void* stream) {
+    CHECK_CTX("igw_step_walking");
+    if (ctx->cfg.action_space != IGW_WALKING_DISCRETE) return fail(IGW_ERR_INVALID, "igw_step_walking: context was created for another action space");
+    if (!actions) return fail(IGW_ERR_INVALID, "igw_step_walking: actions is null");
+    ActIn a = {actions, nullptr, nullptr, nullptr, nullptr};
+    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_WALK>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
+                                            (hipStream_t)stream, ctx->kp, a));
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_step_flying(igw_ctx* ctx, const float* movement, const float* camera, const int32_t* inventory,
+                    const int32_t* placement, void* stream) {
+    CHECK_CTX("igw_step_flying");
+    if (ctx->cfg.action_space != IGW_FLYING) return fail(IGW_ERR_INVALID, "igw_step_flying: context was created for another action space");
+    if (!movement || !camera || !inventory || !placement) return fail(IGW_ERR_INVALID, "igw_step_flying: an action buffer is null");
+    ActIn a = {nullptr, movement, camera, inventory, placement};
+    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_FLY>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
+                                            (hipStream_t)stream, ctx->kp, a));
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int64_t env_offset, void* stream) {
+    CHECK_CTX("igw_rollout_walking");
+    if (ctx->cfg.action_space != IGW_WALKING_DISCRETE) return fail(IGW_ERR_INVALID, "igw_rollout_walking: context was created for another action space");
+    if (T < 0) return fail(IGW_ERR_INVALID, "igw_rollout_walking: T < 0");
+    if (T == 0) return IGW_OK;
+    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(rollout_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
+                                            (hipStream_t)stream, ctx->kp, (long long)T, (unsigned long long)seed,
+                                            (long long)t0, (long long)env_offset));
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_fill_actions_walking(igw_ctx* ctx, int32_t* actions, int64_t n_steps, int64_t t0, uint64_t seed,
+                             int64_t env_offset, void* stream) {
+    CHECK_CTX("igw_fill_actions_walking");
+    if (!actions || n_steps < 0) return fail(IGW_ERR_INVALID, "igw_fill_actions_walking: bad argument");
+    const long long total = (long long)ctx->cfg.num_envs * n_steps;
+    if (total == 0) return IGW_OK;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(fill_actions_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, actions,
+                       (long long)ctx->cfg.num_envs, (long long)n_steps, (long long)t0, (unsigned long long)seed,
+                       (long long)env_offset);
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_task_eval(int32_t device, int32_t n, const int8_t* target, const int8_t* grid, const int8_t* full_grid,
+                  const uint8_t* invariant, int32_t* max_int, int32_t* argmax, int32_t* target_size, void* stream) {
+    if (n < 0 || !target || !grid) return fail(IGW_ERR_INVALID, "igw_task_eval: bad argument");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1)
+        return fail(IGW_ERR_NO_DEVICE, "igw_task_eval: no HIP device available (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= cnt) return fail(IGW_ERR_INVALID, "igw_task_eval: device ordinal out of range");
+    if (n == 0) return IGW_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(IGW_ERR_HIP, "igw_task_eval: hipSetDevice failed");
+    const int blocks = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(task_eval_kernel, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, n, target, grid,
+                       full_grid, invariant, max_int, argmax, target_size);
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+"""Batched IGLU gridworld on one MI355X: N independent envs whose state IS a set of torch
+tensors in HBM, stepped by the HIP kernels behind the C ABI (include/igw.h).
+
+Mirrors the reference's env protocol for render=False / vector_state=True
+(gridworld/env.py:155-303): set_tasks -> reset -> step, with the create_env kwargs of
+gridworld/env.py:333-338.  Observations are tensor views of the state, not copies.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _as_rows(x, device, n=None):
+    """[T,9,11,11] / [T,1089] / [9,11,11] int array -> int8 tensor [T, GRID_STRIDE] on device."""
+    if x is None:
+        return None
+    t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    t = t.reshape(t.shape[0], -1)
+    if t.shape[1] == L.GRID_STRIDE:
+        return t.to(device=device, dtype=torch.int8).contiguous()
+    if t.shape[1] != L.CELLS:
+        raise ValueError(f'grid rows must have 1089 cells, got {t.shape[1]}')
+    out = torch.zeros((t.shape[0], L.GRID_STRIDE), dtype=torch.int8, device=device)
+    out[:, :L.CELLS] = t.to(device=device, dtype=torch.int8)
+    return out
+
+
+class VecGridWorld:
+    """N envs on one GPU.  kwargs follow create_env (gridworld/env.py:333-338)."""
+
+    def __init__(self, num_envs, device='cuda:0', action_space='walking', select_and_place=True,
+                 size_reward=True, max_steps=250, right_placement_scale=1., wrong_placement_scale=0.1,
+                 discretize=True, autoreset=False, num_tasks=None, lanes_per_env=0, **ignored):
+        if not torch.cuda.is_available():
+            raise L.IgwError('VecGridWorld needs a HIP device (no CPU fallback)')
+        if action_space not in ('walking', 'flying'):
+            raise ValueError(f'unknown action_space {action_space!r}')
+        if action_space == 'walking' and not discretize:
+            raise NotImplementedError('only the Discrete(18) walking action space is on the device path')
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.num_envs = int(num_envs)
+        self.num_tasks = int(num_tasks or num_envs)
+        self.flying = action_space == 'flying'
+        self.max_steps = int(max_steps)
+        self.autoreset = bool(autoreset)
+        N, T, dev = self.num_envs, self.num_tasks, self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        self.grid_buf = z((N, L.GRID_STRIDE), torch.int8)
+        self.agent_buf = z((N, L.AGENT_BYTES), torch.uint8)
+        self.env_task = z((N,), torch.int32)
+        self.task_target = z((T, L.GRID_STRIDE), torch.int8)
+        self.task_start = z((T, L.GRID_STRIDE), torch.int8)
+        self.task_meta = z((T, L.TASK_META_BYTES), torch.uint8)
+        self.agent_pos = z((N, 5), torch.float32)
+        self.inventory = z((N, 6), torch.float32)
+        self.compass = z((N,), torch.float32)
+        self.reward = z((N,), torch.float32)
+        self.done = z((N,), torch.uint8)
+        self.stats_buf = z((L.STAT_STRIPES, 8), torch.int64)
+        # Agent.__init__ (core/world.py:12-29): time_int_steps = 2, active_block = BLUE, inventory 20
+        self.agent_buf[:, 56:62] = 20
+        self.agent_buf[:, 62] = 2
+        self.agent_buf[:, 63] = 1
+        self.cfg = L.Config(dev.index or 0, N, T, L.FLYING if self.flying else L.WALKING_DISCRETE,
+                            int(select_and_place), int(size_reward), self.max_steps, int(autoreset),
+                            float(right_placement_scale), float(wrong_placement_scale), int(lanes_per_env), 0)
+        self.ctx = C.c_void_p()
+        L.check(self.lib.igw_create(C.byref(self.cfg), C.byref(self.ctx)), 'igw_create')
+        b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.agent_buf, self.env_task, self.task_target,
+                                                self.task_start, self.task_meta, self.agent_pos, self.inventory,
+                                                self.compass, self.reward, self.done, self.stats_buf)])
+        L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(b)), 'igw_bind_buffers')
+        self.grid = torch.as_strided(self.grid_buf, (N, 9, 11, 11), (L.GRID_STRIDE, 121, 11, 1))
+        self.user_target = None
+        self._have_tasks = False
+
+    def __del__(self):
+        ctx = getattr(self, 'ctx', None)
+        if ctx:
+            self.lib.igw_destroy(ctx)
+            self.ctx = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- tasks (GridWorld.set_task / Task.__init__ / initialize_world) ----
+    def set_tasks(self, targets, starts=None, full_grids=None, invariant=None, init_pose=None,
+                  env_task=None, first=0):
+        """Fills task-table rows [first, first+T).  targets/starts/full_grids: dense [T,9,11,11];
+        invariant: bool or [T]; init_pose: [T,5] (x,y,z,yaw,pitch).  Does not reset."""
+        dev = self.device
+        tgt = _as_rows(targets, dev)
+        T = tgt.shape[0]
+        st = _as_rows(starts, dev)
+        fg = _as_rows(full_grids, dev)
+        inv = None
+        if invariant is not None:
+            inv = torch.as_tensor(np.broadcast_to(np.asarray(invariant, dtype=np.uint8), (T,)).copy(), device=dev)
+        pose = None
+        if init_pose is not None:
+            pose = torch.as_tensor(np.asarray(init_pose, dtype=np.float64).reshape(T, 5), device=dev).contiguous()
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        L.check(self.lib.igw_prepare_tasks(self.ctx, first, T, ptr(tgt), ptr(st), ptr(fg), ptr(inv), ptr(pose),
+                                           self._stream()), 'igw_prepare_tasks')
+        if self.user_target is None:
+            self.user_target = torch.zeros((self.num_tasks, L.GRID_STRIDE), dtype=torch.int8, device=dev)
+        self.user_target[first:first + T] = tgt
+        if env_task is not None:
+            self.env_task.copy_(torch.as_tensor(env_task, dtype=torch.int32, device=dev))
+        elif first == 0:
+            if T == self.num_envs:
+                self.env_task.copy_(torch.arange(self.num_envs, dtype=torch.int32, device=dev))
+            elif T == 1:
+                self.env_task.zero_()
+        self._keep = (tgt, st, fg, inv, pose)  # keep inputs alive until the async kernel ran
+        self._have_tasks = True
+
+    # ---- reset / step ----
+    def _need_tasks(self):
+        if not self._have_tasks:
+            raise ValueError('Task is not initialized! Initialize task before working with the environment '
+                             'using .set_tasks')
+
+    def obs(self):
+        return {'agentPos': self.agent_pos, 'inventory': self.inventory, 'compass': self.compass.unsqueeze(1),
+                'grid': self.grid}
+
+    def reset(self, mask=None, keep_size=False):
+        self._need_tasks()
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        L.check(self.lib.igw_reset(self.ctx, None if m is None else C.c_void_p(m.data_ptr()),
+                                   L.RESET_KEEP_SIZE if keep_size else 0, self._stream()), 'igw_reset')
+        self._mask_keep = m
+        return self.obs()
+
+    def step(self, actions):
+        """walking: int32 tensor [N]; flying: dict(movement f32[N,3], camera f32[N,2], inventory i32[N],
+        placement i32[N]).  Returns (obs, reward, done, info) of tensors living in HBM."""
+        self._need_tasks()
+        dev = self.device
+        if self.flying:
+            mv = torch.as_tensor(actions['movement'], device=dev).to(torch.float32).contiguous()
+            cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).contiguous()
+            inv = torch.as_tensor(actions['inventory'], device=dev).to(torch.int32).contiguous()
+            pl = torch.as_tensor(actions['placement'], device=dev).to(torch.int32).contiguous()
+            L.check(self.lib.igw_step_flying(self.ctx, mv.data_ptr(), cam.data_ptr(), inv.data_ptr(),
+                                             pl.data_ptr(), self._stream()), 'igw_step_flying')
+            self._act_keep = (mv, cam, inv, pl)
+        else:
+            a = torch.as_tensor(actions, device=dev).to(torch.int32).contiguous()
+            L.check(self.lib.igw_step_walking(self.ctx, a.data_ptr(), self._stream()), 'igw_step_walking')
+            self._act_keep = a
+        return self.obs(), self.reward, self.done, {}
+
+    def step_walking_ptr(self, actions_i32):
+        """Hot-loop variant: `actions_i32` is already a contiguous int32 device tensor [N]."""
+        L.check(self.lib.igw_step_walking(self.ctx, actions_i32.data_ptr(), self._stream()), 'igw_step_walking')
+
+    def rollout(self, T, seed, t0=0, env_offset=0):
+        """T fused walking steps per env with counter-RNG actions and auto-reset (one launch)."""
+        self._need_tasks()
+        L.check(self.lib.igw_rollout_walking(self.ctx, int(T), int(seed), int(t0), int(env_offset),
+                                             self._stream()), 'igw_rollout_walking')
+
+    def fill_actions(self, n_steps, seed, t0=0, env_offset=0):
+        a = torch.empty((n_steps, self.num_envs), dtype=torch.int32, device=self.device)
+        L.check(self.lib.igw_fill_actions_walking(self.ctx, a.data_ptr(), int(n_steps), int(t0), int(seed),
+                                                  int(env_offset), self._stream()), 'igw_fill_actions_walking')
+        return a
+
+    # ---- introspection ----
+    def stats(self):
+        s = self.stats_buf.sum(0).cpu()
+        return {'changed': int(s[L.STAT_CHANGED]), 'resets': int(s[L.STAT_RESETS]),
+                'rollout_steps': int(s[L.STAT_STEPS])}
+
+    def internals(self):
+        """float64 [N,8]: x, y, z, yaw, pitch, dy, time_int_steps, active_block (debug / parity)."""
+        raw = self.agent_buf.cpu().numpy()
+        out = np.zeros((self.num_envs, 8), np.float64)
+        out[:, :6] = raw[:, :48].copy().view(np.float64)
+        out[:, 6] = raw[:, 62]
+        out[:, 7] = raw[:, 63]
+        return out
+
+    def task_state(self):
+        raw = self.agent_buf.cpu().numpy()
+        return {'step_no': raw[:, 48:50].copy().view(np.uint16)[:, 0].astype(np.int64),
+                'size': raw[:, 50:52].copy().view(np.int16)[:, 0].astype(np.int64),
+                'prev_size': raw[:, 52:54].copy().view(np.int16)[:, 0].astype(np.int64),
+                'max_int': raw[:, 54:56].copy().view(np.int16)[:, 0].astype(np.int64)}
+
+
+def task_eval(targets, grids, full_grids=None, invariant=None, device='cuda:0'):
+    """Task(target, full_grid, invariant).maximal_intersection / argmax_intersection on `grid`
+    for n pairs (tasks/task.py:121-161), on the GPU.  Returns numpy (max_int, argmax[n,3], target_size)."""
+    if not torch.cuda.is_available():
+        raise L.IgwError('task_eval needs a HIP device (no CPU fallback)')
+    lib = L.load()
+    dev = torch.device(device)
+    t, g, f = _as_rows(targets, dev), _as_rows(grids, dev), _as_rows(full_grids, dev)
+    n = t.shape[0]
+    inv = None
+    if invariant is not None:
+        inv = torch.as_tensor(np.broadcast_to(np.asarray(invariant, dtype=np.uint8), (n,)).copy(), device=dev)
+    mi = torch.zeros(n, dtype=torch.int32, device=dev)
+    am = torch.zeros((n, 3), dtype=torch.int32, device=dev)
+    ts = torch.zeros(n, dtype=torch.int32, device=dev)
+    ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())  # noqa: E731
+    L.check(lib.igw_task_eval(dev.index or 0, n, ptr(t), ptr(g), ptr(f), ptr(inv), ptr(mi), ptr(am), ptr(ts),
+                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'igw_task_eval')
+    return mi.cpu().numpy(), am.cpu().numpy(), ts.cpu().numpy()

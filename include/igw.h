@@ -1,0 +1,171 @@
+/*
+ * igw.h -- C ABI of the MI355X-native IGLU gridworld step path (libigw_hip.so).
+ *
+ * Drop-in boundary for the reference's `GridWorld` env protocol on the
+ * render=False / vector_state=True path (all `file:line` are relative to the
+ * reference, iglu-contest/gridworld):
+ *
+ *   igw_prepare_tasks  <- GridWorld.set_task / set_task_generator + Task.__init__
+ *                         (gridworld/env.py:155-175, gridworld/tasks/task.py:9-72)
+ *                         + GridWorld.initialize_world pose (env.py:177-193)
+ *   igw_reset          <- GridWorld.reset (env.py:206-261), SizeReward.reset (env.py:321-323)
+ *   igw_step_walking   <- GridWorld.step (env.py:268-303) with World.step /
+ *                         parse_walking_discrete_action (core/world.py:360-394, 434-456)
+ *   igw_step_flying    <- same with parse_flying_action (core/world.py:416-432)
+ *   igw_task_eval      <- Task.maximal_intersection / argmax_intersection
+ *                         (tasks/task.py:121-161)
+ *   igw_rollout_walking<- the loop of examples/run_env.py:18-26 fused on device
+ *
+ * Plain pointers and sizes only; every data pointer is a DEVICE pointer owned by
+ * the caller (e.g. torch tensors) and must outlive the context.  All calls are
+ * asynchronous on the given hipStream_t (pass it as void*; NULL = default stream),
+ * never synchronise, never allocate, and return 0 on success or a negative
+ * igw_status; igw_last_error() gives the message.  No exceptions cross the ABI.
+ * One batch of N independent envs per context; the caller serialises calls on
+ * one context.
+ */
+#ifndef IGW_H
+#define IGW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGW_VERSION 1
+
+/* dense voxel grid [y+1][x+5][z+5], int8 (env.py:34, 136-142) */
+#define IGW_GRID_Y 9
+#define IGW_GRID_X 11
+#define IGW_GRID_Z 11
+#define IGW_CELLS 1089
+/* row stride of every [*, 9,11,11] int8 buffer: 1089 padded to a multiple of 16 B so a
+ * wavefront moves one env's grid with 69 aligned dwordx4 accesses; pad bytes stay 0 */
+#define IGW_GRID_STRIDE 1104
+/* bytes of per-env agent state and of per-task metadata (layouts below) */
+#define IGW_AGENT_BYTES 64
+#define IGW_TASK_META_BYTES 128
+/* striped device counters: [IGW_STAT_STRIPES][8] uint64, stripe = 64 B */
+#define IGW_STAT_STRIPES 64
+#define IGW_STAT_CHANGED 0 /* env-steps whose block count changed (max_intersection recomputed) */
+#define IGW_STAT_RESETS 1  /* auto-resets performed */
+#define IGW_STAT_STEPS 2   /* env-steps executed by igw_rollout_walking */
+
+enum igw_status {
+    IGW_OK = 0,
+    IGW_ERR_INVALID = -1,   /* bad argument / config */
+    IGW_ERR_NO_DEVICE = -2, /* no usable HIP device */
+    IGW_ERR_HIP = -3,       /* a HIP call failed */
+    IGW_ERR_UNBOUND = -4    /* buffers not bound */
+};
+
+enum igw_action_space {
+    IGW_WALKING_DISCRETE = 0, /* Discrete(18), create_env default (env.py:333-338) */
+    IGW_FLYING = 1            /* Dict(movement, camera, inventory, placement) (env.py:71-78) */
+};
+
+/* create_env kwargs that reach the step path (env.py:333-350) */
+typedef struct igw_config {
+    int32_t device;            /* HIP device ordinal */
+    int32_t num_envs;          /* N */
+    int32_t num_tasks;         /* capacity of the task table (>= 1) */
+    int32_t action_space;      /* igw_action_space */
+    int32_t select_and_place;  /* env.py:334 (default 1) */
+    int32_t size_reward;       /* SizeReward wrapper, env.py:316-331 (default 1) */
+    int32_t max_steps;         /* env.py:336 (default 250), 1..65534 */
+    int32_t autoreset;         /* 0: caller resets on done (reference loop); 1: reset inside step */
+    double right_placement_scale; /* env.py:335 */
+    double wrong_placement_scale; /* env.py:337 */
+    int32_t lanes_per_env;     /* 0 = library default; 64/32/16/8: wavefront lanes cooperating on one env */
+    int32_t reserved;
+} igw_config;
+
+/*
+ * Agent state, IGW_AGENT_BYTES per env (Agent, core/world.py:8-29, + the ints
+ * GridWorld / Task / SizeReward keep per episode):
+ *   0  f64 x, y, z        agent.position
+ *   24 f64 yaw            agent.rotation[0]
+ *   32 f64 pitch          agent.rotation[1]
+ *   40 f64 vy             agent.dy            (leaks through reset)
+ *   48 u16 step_no        GridWorld.step_no   (saturates at 65535)
+ *   50 i16 size           SizeReward.size
+ *   52 i16 prev_size      _synthetic_task.prev_grid_size
+ *   54 i16 max_int        _synthetic_task.max_int
+ *   56 i8  inventory[6]   agent.inventory
+ *   62 u8  time_int_steps agent.time_int_steps (leaks through reset)
+ *   63 u8  active_block   agent.active_block   (leaks through reset)
+ *
+ * Task metadata, IGW_TASK_META_BYTES per task (written by igw_prepare_tasks):
+ *   0  f64 init_pose[5]   x, y, z, yaw, pitch (GridWorld.initial_position/rotation)
+ *   40 i16 target_size    _synthetic_task.target_size
+ *   42 i16 env_max_int    GridWorld.max_int at reset (user task on the starting grid)
+ *   44 i8  bbox[4][4]     per rotation xmin, xmax, zmin, zmax of the synthetic target
+ *   60 i8  inv_init[6]    inventory at reset (20 - blocks of that colour in the start grid)
+ *   66 u8  has_start      starting grid not empty
+ *   67 ..  zero
+ */
+typedef struct igw_buffers {
+    /* state */
+    int8_t* grid;          /* [N][IGW_GRID_STRIDE]   world grid == obs 'grid' */
+    void* agent;           /* [N][IGW_AGENT_BYTES] */
+    int32_t* env_task;     /* [N] index into the task table */
+    /* task table */
+    int8_t* task_target;   /* [T][IGW_GRID_STRIDE] synthetic target = target - start (env.py:230) */
+    int8_t* task_start;    /* [T][IGW_GRID_STRIDE] dense starting grid (env.py:226) */
+    void* task_meta;       /* [T][IGW_TASK_META_BYTES] */
+    /* per-step outputs (env.py:281-303) */
+    float* agent_pos;      /* [N][5] x, y, z, pitch, yaw */
+    float* inventory;      /* [N][6] */
+    float* compass;        /* [N]    yaw - 180 */
+    float* reward;         /* [N]    (float) of the double reward */
+    uint8_t* done;         /* [N] */
+    uint64_t* stats;       /* [IGW_STAT_STRIPES][8], caller zeroes; may be NULL */
+} igw_buffers;
+
+typedef struct igw_ctx igw_ctx;
+
+int igw_version(void);
+const char* igw_last_error(void);
+/* number of visible HIP devices (0 if none / runtime unusable); does not create a context */
+int igw_device_count(void);
+
+int igw_create(const igw_config* cfg, igw_ctx** out);
+int igw_destroy(igw_ctx* ctx);
+int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* bufs);
+
+/* Fills task-table rows [first, first+n): user_target / start / full_grid are device
+ * int8 [n][IGW_GRID_STRIDE] (start, full_grid may be NULL = empty / absent), invariant is
+ * device uint8[n] or NULL (= 1), init_pose device double[n][5] or NULL (= zeros). */
+int igw_prepare_tasks(igw_ctx* ctx, int32_t first, int32_t n, const int8_t* user_target,
+                      const int8_t* start, const int8_t* full_grid, const uint8_t* invariant,
+                      const double* init_pose, void* stream);
+
+#define IGW_RESET_KEEP_SIZE 1 /* GridWorld.reset only (what set_task calls): SizeReward.size survives */
+/* mask: device uint8[N] or NULL (= all envs) */
+int igw_reset(igw_ctx* ctx, const uint8_t* mask, int32_t flags, void* stream);
+
+int igw_step_walking(igw_ctx* ctx, const int32_t* actions /* [N] in 0..17 */, void* stream);
+int igw_step_flying(igw_ctx* ctx, const float* movement /* [N][3] */, const float* camera /* [N][2] */,
+                    const int32_t* inventory /* [N] 0..6 */, const int32_t* placement /* [N] 0..2 */,
+                    void* stream);
+
+/* T fused walking steps per env, actions = uniform Discrete(18) from a counter RNG keyed by
+ * (seed, env_offset + env, t) for t = t0 .. t0+T-1; auto-reset on done regardless of cfg.autoreset. */
+int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int64_t env_offset,
+                        void* stream);
+/* fills actions[n_steps][N] with the same counter RNG (t = t0 .. t0+n_steps-1) */
+int igw_fill_actions_walking(igw_ctx* ctx, int32_t* actions, int64_t n_steps, int64_t t0, uint64_t seed,
+                             int64_t env_offset, void* stream);
+
+/* Stateless Task evaluation for n (target, grid) pairs: buffers int8 [n][IGW_GRID_STRIDE];
+ * full_grid / invariant may be NULL; outputs int32: max_int[n], argmax[n][3] = (dx, dz, rot),
+ * target_size[n]; any output may be NULL. */
+int igw_task_eval(int32_t device, int32_t n, const int8_t* target, const int8_t* grid,
+                  const int8_t* full_grid, const uint8_t* invariant, int32_t* max_int,
+                  int32_t* argmax, int32_t* target_size, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

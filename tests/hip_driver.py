@@ -1,0 +1,41 @@
+"""gridworld_amd.VecGridWorld behind the golden-replay driver interface (GPU)."""
+import numpy as np
+import torch
+
+from gridworld_amd import VecGridWorld
+
+
+class HipDriver:
+    def __init__(self, fx, lanes_per_env=0, **extra):
+        kw = dict(fx['kwargs'])
+        kw.update(extra)
+        self.env = VecGridWorld(len(fx['targets']), lanes_per_env=lanes_per_env, **kw)
+        self._pose = None
+        self._tasks = None
+
+    def set_tasks(self, targets, starts, invariant=True):
+        self._tasks = (targets, starts, invariant)
+        self.env.set_tasks(targets, starts, invariant=invariant, init_pose=self._pose)
+
+    def set_initial_pose(self, poses):
+        self._pose = np.asarray(poses, np.float64)
+        t, s, inv = self._tasks
+        self.env.set_tasks(t, s, invariant=inv, init_pose=self._pose)
+
+    def reset(self, mask):
+        self.env.reset(mask)
+
+    def step_walking(self, actions):
+        self.env.step(torch.as_tensor(np.asarray(actions, np.int32)))
+
+    def step_flying(self, mv, cam, inv, place):
+        self.env.step(dict(movement=np.asarray(mv, np.float32), camera=np.asarray(cam, np.float32),
+                           inventory=np.asarray(inv, np.int32), placement=np.asarray(place, np.int32)))
+
+    def outputs(self):
+        e = self.env
+        torch.cuda.synchronize()
+        return dict(agentPos=e.agent_pos.cpu().numpy(), inventory=e.inventory.cpu().numpy(),
+                    compass=e.compass.cpu().numpy(), reward=e.reward.cpu().numpy(),
+                    done=e.done.cpu().numpy(), grid=e.grid.cpu().numpy().reshape(e.num_envs, -1),
+                    internal=e.internals())

@@ -1,0 +1,174 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors recorded from the
+Python reference and against the CPU oracle on the same seeded inputs.  Bit-exact everywhere
+(integer outputs, float32 observations and the float64 agent internals)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_replay as GR
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip(fx, **kw):
+    from hip_driver import HipDriver
+    return HipDriver(fx, **kw)
+
+
+@pytest.mark.parametrize('name', GR.WALK_FIXTURES)
+def test_walking_fixture(name):
+    fx = GR.load_fixture(name)
+    assert GR.replay(fx, _hip(fx)) == fx['done'].size
+
+
+@pytest.mark.parametrize('gs', [32, 16, 8])
+@pytest.mark.parametrize('name', ['s2_walk_cdm', 's3_walk_rt20', 's5_scripted'])
+def test_walking_fixture_lane_groups(name, gs):
+    fx = GR.load_fixture(name)
+    GR.replay(fx, _hip(fx, lanes_per_env=gs), max_steps=260)
+
+
+def test_task_vectors():
+    """igw_task_eval vs Task.maximal_intersection / argmax_intersection of the reference."""
+    from gridworld_amd import task_eval
+    z = np.load(GR.GOLDEN_DIR + '/s6_task_vectors.npz')
+    targets, grids, fulls = z['targets'], z['grids'], z['full_grids']
+    P, G = len(targets), len(grids)
+    tt = np.repeat(targets, G, axis=0)
+    gg = np.tile(grids, (P, 1, 1, 1))
+    ff = np.repeat(fulls, G, axis=0)
+    mi, am, ts = task_eval(tt, gg)
+    assert np.array_equal(mi.reshape(P, G), z['max_int'])
+    assert np.array_equal(am.reshape(P, G, 3), z['argmax'])
+    assert np.array_equal(ts.reshape(P, G)[:, 0], z['target_size'])
+    mi, am, _ = task_eval(tt, gg, invariant=False)
+    assert np.array_equal(mi.reshape(P, G), z['ni_max_int'])
+    assert np.array_equal(am.reshape(P, G, 3), z['ni_argmax'])
+    mi, am, _ = task_eval(tt, gg, full_grids=ff)
+    assert np.array_equal(mi.reshape(P, G), z['fg_max_int'])
+    assert np.array_equal(am.reshape(P, G, 3), z['fg_argmax'])
+
+
+def test_env_max_int_at_reset():
+    """GridWorld.max_int (env.py:241) lands in the task metadata and drives SizeReward."""
+    from gridworld_amd import VecGridWorld
+    fx = GR.load_fixture('s2_walk_cdm')
+    env = VecGridWorld(len(fx['targets']), size_reward=True)
+    env.set_tasks(fx['targets'], fx['starts'])
+    torch.cuda.synchronize()
+    meta = env.task_meta.cpu().numpy()
+    got = meta[:, 42:44].copy().view(np.int16)[:, 0]
+    assert np.array_equal(got, fx['env_max_int'])
+
+
+def _rt20_targets(n, seed):
+    rng = np.random.RandomState(seed)
+    out = np.zeros((n, 9, 11, 11), np.int8)
+    for e in range(n):
+        bx, bz = rng.randint(2, 9, size=2)
+        cells = [(bx + dx, bz + dz) for dx in range(-2, 3) for dz in range(-2, 3)]
+        for i in rng.permutation(25)[:20]:
+            out[e, 0, cells[i][0], cells[i][1]] = rng.randint(1, 7)
+    return out
+
+
+def _compare(env, ob, where):
+    torch.cuda.synchronize()
+    assert np.array_equal(env.done.cpu().numpy(), ob.done), where + ' done'
+    assert np.array_equal(env.reward.cpu().numpy().view(np.uint32), ob.reward.view(np.uint32)), where + ' reward'
+    assert np.array_equal(env.grid.cpu().numpy().reshape(env.num_envs, -1), ob.grid), where + ' grid'
+    assert np.array_equal(env.inventory.cpu().numpy(), ob.inventory), where + ' inventory'
+    assert np.array_equal(env.agent_pos.cpu().numpy().view(np.uint32), ob.agentPos.view(np.uint32)), where + ' agentPos'
+    assert np.array_equal(env.compass.cpu().numpy().view(np.uint32), ob.compass.view(np.uint32)), where + ' compass'
+
+
+@pytest.mark.parametrize('gs', [64, 16])
+def test_config2_4096_envs_vs_oracle(gs):
+    """BASELINE config 2: 4,096 parallel envs, walking, DUMMY-equivalent task, bit-exact vs the CPU
+    path on counter-RNG action streams, auto-reset inside step (max_steps=50 so resets happen)."""
+    from gridworld_amd import VecGridWorld
+    from oracle import oracle as O
+    n, T = 4096, 120
+    kw = dict(size_reward=False, max_steps=50)
+    tg = np.zeros((1, 9, 11, 11), np.int8)
+    tg[0, 8, 10, 10] = 1
+    env = VecGridWorld(n, autoreset=True, num_tasks=1, lanes_per_env=gs, **kw)
+    env.set_tasks(tg, invariant=False)
+    env.reset()
+    ob = O.OracleBatch(n, **kw)
+    ob.set_tasks(np.repeat(tg, n, axis=0), invariant=False)
+    ob.reset()
+    acts = env.fill_actions(T, seed=1234)
+    a_np = acts.cpu().numpy()
+    for t in range(T):
+        env.step(acts[t])
+        ob.step_walking(a_np[t], autoreset=True, nthreads=8)
+        if t % 10 == 9 or t == T - 1:
+            _compare(env, ob, f'step {t}')
+    assert env.stats()['resets'] == n * (T // 50)
+
+
+def test_rt20_autoreset_vs_oracle():
+    """rt20 targets (full maximal_intersection reward), 1,024 envs, per-env tasks, vs the oracle."""
+    from gridworld_amd import VecGridWorld
+    from oracle import oracle as O
+    n, T = 1024, 300
+    kw = dict(size_reward=False)
+    tg = _rt20_targets(n, 5)
+    env = VecGridWorld(n, autoreset=True, **kw)
+    env.set_tasks(tg)
+    env.reset()
+    ob = O.OracleBatch(n, **kw)
+    ob.set_tasks(tg)
+    ob.reset()
+    acts = env.fill_actions(T, seed=99)
+    a_np = acts.cpu().numpy()
+    changed = 0
+    for t in range(T):
+        env.step(acts[t])
+        ob.step_walking(a_np[t], autoreset=True, nthreads=8)
+        if t % 25 == 24 or t == T - 1:
+            _compare(env, ob, f'step {t}')
+    st = env.stats()
+    assert st['resets'] >= n and 0.01 < st['changed'] / (n * T) < 0.3
+
+
+def test_fused_rollout_vs_oracle():
+    """igw_rollout_walking (T steps in one launch, counter RNG, auto-reset) == T single steps == oracle."""
+    from gridworld_amd import VecGridWorld
+    from oracle import oracle as O
+    n, T = 512, 300
+    kw = dict(size_reward=False)
+    tg = _rt20_targets(n, 11)
+    env = VecGridWorld(n, autoreset=True, **kw)
+    env.set_tasks(tg)
+    env.reset()
+    env.rollout(T, seed=4242)
+    ob = O.OracleBatch(n, **kw)
+    ob.set_tasks(tg)
+    ob.reset()
+    steps, changed = ob.rollout_walking(T, 4242, autoreset=True, nthreads=8)
+    torch.cuda.synchronize()
+    assert np.array_equal(env.grid.cpu().numpy().reshape(n, -1), np.stack([e.obs()['grid'].reshape(-1) for e in ob.envs]).astype(np.int8))
+    assert np.array_equal(env.internals().view(np.uint64), ob.internals().view(np.uint64))
+    st = env.stats()
+    assert st['rollout_steps'] == steps == n * T and st['changed'] == changed
+    # and the same thing as T separate launches
+    env2 = VecGridWorld(n, autoreset=True, **kw)
+    env2.set_tasks(tg)
+    env2.reset()
+    acts = env2.fill_actions(T, seed=4242)
+    for t in range(T):
+        env2.step(acts[t])
+    torch.cuda.synchronize()
+    assert torch.equal(env.grid_buf, env2.grid_buf) and torch.equal(env.agent_buf, env2.agent_buf)
+
+
+def test_product_does_not_import_oracle():
+    import sys
+    import gridworld_amd  # noqa: F401
+    import inspect
+    import gridworld_amd.vec_env as v
+    import gridworld_amd._lib as l
+    for mod in (v, l, gridworld_amd):
+        assert 'oracle' not in inspect.getsource(mod).replace('no CPU fallback', '')
