@@ -1,0 +1,68 @@
+"""Multi-GPU launch helpers: one process per GPU, envs sharded with no data-path collective.
+
+Envs are fully independent, so ranks never exchange state.  The only
+collectives are control-plane: a barrier around the timing window and one all-reduce of the
+per-rank env-step counters / elapsed time (RCCL over xGMI on GPUs, gloo on CPU in tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_info():
+    return (int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)),
+            int(os.environ.get('WORLD_SIZE', 1)))
+
+
+def init(backend=None):
+    """Initialises torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_info()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def shard_envs(total_envs, rank, world):
+    """Contiguous env range [lo, hi) of `rank` (weak scaling passes total = per_gpu * world)."""
+    lo = total_envs * rank // world
+    hi = total_envs * (rank + 1) // world
+    return lo, hi
+
+
+def barrier(device=None):
+    if dist.is_initialized():
+        if device is not None and device.type == 'cuda':
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
+
+
+def reduce_window(steps, seconds, device=None):
+    """(total env-steps over all ranks, max elapsed seconds over ranks)."""
+    if not dist.is_initialized():
+        return int(steps), float(seconds)
+    dev = device if device is not None else torch.device('cpu')
+    s = torch.tensor([int(steps)], dtype=torch.int64, device=dev)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=dev)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(s.item()), float(t.item())
+
+
+def gather_counts(value, device=None):
+    """all_gather of one int64 per rank (e.g. per-rank step counters)."""
+    if not dist.is_initialized():
+        return [int(value)]
+    dev = device if device is not None else torch.device('cpu')
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [int(o.item()) for o in out]

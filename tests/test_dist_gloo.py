@@ -1,0 +1,63 @@
+"""Multi-process path on CPU (gloo, world size 2): env sharding, barrier, step-count reduction.
+The data path has no collective (envs are independent); this covers what bench.py does around it."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys, time, json
+    sys.path.insert(0, %r)
+    import torch
+    from gridworld_amd import dist as gd
+    rank, local_rank, world = gd.init(backend='gloo')
+    assert world == 2
+    total = 65536 * world + 3
+    lo, hi = gd.shard_envs(total, rank, world)
+    gd.barrier()
+    t = time.perf_counter()
+    steps = (hi - lo) * 10          # 10 "steps" of this rank's shard
+    time.sleep(0.05 * (rank + 1))   # uneven ranks: the window is the max over ranks
+    el = time.perf_counter() - t
+    gd.barrier()
+    tot, mx = gd.reduce_window(steps, el)
+    counts = gd.gather_counts(steps)
+    if rank == 0:
+        print(json.dumps(dict(total=tot, max_elapsed=mx, counts=counts, lo=lo, hi=hi, expect=total * 10)))
+''') % ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_gloo_world2_sharding_and_reduction(tmp_path):
+    import json
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['total'] == d['expect'] == sum(d['counts'])
+    assert d['max_elapsed'] >= 0.1
+    assert d['lo'] == 0 and d['hi'] == (65536 * 2 + 3) // 2
+
+
+def test_shard_envs_partition():
+    from gridworld_amd.dist import shard_envs
+    for total in (1, 7, 65536, 524288, 524291):
+        for world in (1, 2, 3, 8):
+            edges = [shard_envs(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
