@@ -26,14 +26,59 @@ class BatchOut(C.Structure):
                 ('reward', C.c_void_p), ('done', C.c_void_p), ('grid', C.c_void_p)]
 
 
+_TRIG_PATH = os.path.join(_HERE, 'libigw_trig_host.so')
+_CSRC = os.path.join(_HERE, '..', 'gridworld_amd', 'csrc')
+
+
+def _stale(lib, srcs):
+    return not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs)
+
+
 def build(force=False):
-    """Compiles oracle/libigw_oracle.so with gcc (oracle/Makefile)."""
+    """Compiles oracle/libigw_oracle.so and oracle/libigw_trig_host.so (oracle/Makefile)."""
     src = [os.path.join(_HERE, f) for f in ('igw_oracle.c', 'igw_oracle.h', 'Makefile')]
-    if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in src):
+    if force or _stale(_LIB_PATH, src):
         subprocess.run(['make', '-C', _HERE, '-B', 'libigw_oracle.so'], check=True,
                        stdout=subprocess.DEVNULL)
+    tsrc = [os.path.join(_HERE, 'igw_trig_host.cpp'), os.path.join(_CSRC, 'igw_trig.h'),
+            os.path.join(_CSRC, 'igw_trig_tables.h')]
+    if force or _stale(_TRIG_PATH, tsrc):
+        subprocess.run(['make', '-C', _HERE, '-B', 'libigw_trig_host.so'], check=True,
+                       stdout=subprocess.DEVNULL)
     return _LIB_PATH
+
+
+_trig = None
+
+
+def trig_host():
+    """Host compile of the product's igw_trig.h (sin / cos / atan2 as the HIP kernels compute them)."""
+    global _trig
+    if _trig is None:
+        build()
+        T = C.CDLL(_TRIG_PATH)
+        for f in (T.igw_host_sin, T.igw_host_cos):
+            f.restype = C.c_double
+            f.argtypes = [C.c_double]
+        T.igw_host_atan2.restype = C.c_double
+        T.igw_host_atan2.argtypes = [C.c_double, C.c_double]
+        T.igw_host_sincos_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        T.igw_host_atan2_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        _trig = T
+    return _trig
+
+
+def use_device_trig(on):
+    """Oracle trig mode: libm (= the Python reference, default) or the product's own sincos/atan2
+    ("device-trig" mode: the oracle then matches the HIP kernels bit-for-bit in flying mode too)."""
+    L = lib()
+    L.igo_set_trig.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if on:
+        T = trig_host()
+        L.igo_set_trig(C.cast(T.igw_host_sin, C.c_void_p), C.cast(T.igw_host_cos, C.c_void_p),
+                       C.cast(T.igw_host_atan2, C.c_void_p))
+    else:
+        L.igo_set_trig(None, None, None)
 
 
 _lib = None
