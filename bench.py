@@ -96,6 +96,7 @@ def main():
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
+    ap.add_argument('--debug-flags', type=int, default=0, help='timing-only ablations (results invalid)')
     args = ap.parse_args()
 
     from gridworld_amd import VecGridWorld, dist as gdist, workloads
@@ -110,7 +111,7 @@ def main():
     env_offset = rank * N  # rank-offset RNG streams / task seeds
 
     env = VecGridWorld(N, device=device, action_space='walking', size_reward=False, max_steps=250,
-                       autoreset=True, lanes_per_env=args.lanes_per_env)
+                       autoreset=True, lanes_per_env=args.lanes_per_env, debug_flags=args.debug_flags)
     env.set_tasks(workloads.rt20(N, seed=args.seed + rank, device=device))
     env.reset()
     # actions for warmup + timed steps are generated on the device before the clock starts

@@ -13,6 +13,7 @@ GRID_STRIDE = 1104
 CELLS = 1089
 AGENT_BYTES = 64
 TASK_META_BYTES = 128
+OCC_WORDS = 36
 STAT_STRIPES = 64
 STAT_CHANGED, STAT_RESETS, STAT_STEPS = 0, 1, 2
 WALKING_DISCRETE, FLYING = 0, 1
@@ -37,9 +38,9 @@ class Config(C.Structure):
 
 
 class Buffers(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('grid', 'agent', 'env_task', 'task_target', 'task_start',
-                                          'task_meta', 'agent_pos', 'inventory', 'compass', 'reward',
-                                          'done', 'stats')]
+    _fields_ = [(n, C.c_void_p) for n in ('grid', 'occ', 'agent', 'env_task', 'task_target', 'task_start',
+                                          'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass',
+                                          'reward', 'done', 'stats')]
 
 
 _lib = None

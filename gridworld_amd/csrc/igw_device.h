@@ -31,6 +31,9 @@ constexpr int LEVEL = 121;           // cells per y level
 constexpr int HIST_BINS = 4 * 121;
 constexpr int HIST_WORDS = HIST_BINS / 2;  // 242
 constexpr int HIST_PAD = 256;
+// occupancy bitmap of the 1089 cells (bit = cell index): the per-step working set of the physics
+constexpr int OCC_WORDS = IGW_OCC_WORDS;  // 36 dwords = 144 B per env in HBM
+constexpr int OCC_PITCH = 37;             // LDS pitch (odd => conflict-free when one lane owns one env)
 
 // gridworld/utils.py:9-24 and core/world.py:9
 constexpr double WALKING_SPEED = 5.0;
@@ -46,7 +49,9 @@ struct alignas(16) AgentRec {  // layout documented in include/igw.h
     double x, y, z, yaw, pitch, vy;
     uint16_t step_no;
     int16_t size, prev_size, max_int;
-    uint64_t inv_tis_active;  // bytes 0..5 inventory (int8), byte 6 time_int_steps, byte 7 active_block
+    // bytes 0..5 inventory (int8); bits 48-49 time_int_steps code (2,4,8,12), bits 50-52 active_block,
+    // bits 53-63 target_size of the synthetic task (copied from the task table by reset)
+    uint64_t inv_pack;
 };
 static_assert(sizeof(AgentRec) == IGW_AGENT_BYTES, "agent record layout");
 
@@ -62,12 +67,15 @@ static_assert(sizeof(TaskMeta) == IGW_TASK_META_BYTES, "task meta layout");
 
 struct KParams {
     int32_t n_envs, select_and_place, size_reward, max_steps, autoreset;
+    int32_t debug;  // timing-only ablation switches (igw_config.reserved); 0 in every parity / bench run
     double right_scale, wrong_scale;
     int8_t* grid;
+    uint32_t* occ;
     AgentRec* agent;
     const int32_t* env_task;
     const int8_t* task_target;
     const int8_t* task_start;
+    const uint32_t* task_start_occ;
     const TaskMeta* task_meta;
     float* agent_pos;
     float* inventory;
@@ -92,16 +100,21 @@ struct Grp {
     }
     // ballot restricted to this group, bit i = lane i of the group
     __device__ uint64_t ballot(bool p) const {
+        if constexpr (GS == 1) return p ? 1ull : 0ull;
         uint64_t m = __ballot(p);
         if constexpr (GS == 64) return m;
         else return (m >> (g * GS)) & ((1ull << GS) - 1ull);
     }
     // value held by lane `src` of this group (src uniform within the group)
     __device__ int bcast(int v, int src) const {
-        if constexpr (GS == 64) return __builtin_amdgcn_readlane(v, src);
+        if constexpr (GS == 1) return v;
+        else if constexpr (GS == 64) return __builtin_amdgcn_readlane(v, src);
         else return __shfl(v, src, GS);
     }
-    __device__ int shfl_up1(int v) const { return __shfl_up(v, 1, GS); }
+    __device__ int shfl_up1(int v) const {
+        if constexpr (GS == 1) return v;
+        else return __shfl_up(v, 1, GS);
+    }
 };
 
 __device__ inline void wave_sync() {
@@ -141,7 +154,7 @@ struct Env {  // uniform across the lanes of a group
     double x, y, z, yaw, pitch, vy;
     int step_no, size, prev_size, max_int;
     uint64_t inv;  // 6 x int8
-    int tis, active;
+    int tis, active, target_size;
 };
 
 __device__ inline int inv_get(uint64_t inv, int i) { return (int)(int8_t)(inv >> (8 * i)); }
@@ -156,16 +169,19 @@ __device__ inline void env_load(Env& e, const AgentRec* rec) {
     const AgentRec r = *rec;
     e.x = r.x; e.y = r.y; e.z = r.z; e.yaw = r.yaw; e.pitch = r.pitch; e.vy = r.vy;
     e.step_no = r.step_no; e.size = r.size; e.prev_size = r.prev_size; e.max_int = r.max_int;
-    e.inv = r.inv_tis_active & 0x0000ffffffffffffull;
-    e.tis = (int)((r.inv_tis_active >> 48) & 0xff);
-    e.active = (int)(r.inv_tis_active >> 56);
+    e.inv = r.inv_pack & 0x0000ffffffffffffull;
+    const int code = (int)((r.inv_pack >> 48) & 3);
+    e.tis = code == 0 ? 2 : code == 1 ? 4 : code == 2 ? 8 : 12;
+    e.active = (int)((r.inv_pack >> 50) & 7);
+    e.target_size = (int)(r.inv_pack >> 53);
 }
 __device__ inline void env_store(const Env& e, AgentRec* rec) {
     AgentRec r;
     r.x = e.x; r.y = e.y; r.z = e.z; r.yaw = e.yaw; r.pitch = e.pitch; r.vy = e.vy;
     r.step_no = (uint16_t)e.step_no; r.size = (int16_t)e.size;
     r.prev_size = (int16_t)e.prev_size; r.max_int = (int16_t)e.max_int;
-    r.inv_tis_active = e.inv | ((uint64_t)(e.tis & 0xff) << 48) | ((uint64_t)(e.active & 0xff) << 56);
+    const uint64_t code = e.tis == 2 ? 0 : e.tis == 4 ? 1 : e.tis == 8 ? 2 : 3;
+    r.inv_pack = e.inv | (code << 48) | ((uint64_t)(e.active & 7) << 50) | ((uint64_t)(e.target_size & 0x7ff) << 53);
     *rec = r;
 }
 
@@ -181,20 +197,15 @@ __device__ inline bool build_zone_i(int x, int y, int z) {
 }
 __device__ inline int cell_of(int x, int y, int z) { return (y + 1) * LEVEL + (x + 5) * 11 + (z + 5); }
 
-// `key in world` / `world[key]` answered from the dense grid in LDS plus the fixed ground plane
+// `key in world` answered from the env's occupancy bitmap in LDS plus the fixed ground plane
 // (World._initialize, core/world.py:60-71: y=-2, |x|,|z|<=18, WHITE(-1) over the build zone else GREY(0)).
-__device__ inline bool world_lookup(const int8_t* grid_s, int x, int y, int z, int& colour) {
-    if (y == -2) {
-        colour = (x >= -5 && x <= 5 && z >= -5 && z <= 5) ? -1 : 0;
-        return x >= -18 && x <= 18 && z >= -18 && z <= 18;
-    }
+// Colours live in the int8 grid row in HBM and are only fetched for the one block a break hits.
+__device__ inline bool occ_test(const uint32_t* occ_s, int idx) { return (occ_s[idx >> 5] >> (idx & 31)) & 1u; }
+
+__device__ inline bool world_has(const uint32_t* occ_s, int x, int y, int z) {
+    if (y == -2) return x >= -18 && x <= 18 && z >= -18 && z <= 18;
     if (!build_zone_i(x, y, z)) return false;
-    colour = grid_s[cell_of(x, y, z)];
-    return colour != 0;
-}
-__device__ inline bool world_has(const int8_t* grid_s, int x, int y, int z) {
-    int c;
-    return world_lookup(grid_s, x, y, z, c);
+    return occ_test(occ_s, cell_of(x, y, z));
 }
 
 // ---------------------------------------------------------------- trig front-end
@@ -219,7 +230,7 @@ __device__ inline void sincos_deg(const TrigCtx& t, double deg, double& s, doubl
 
 // ---------------------------------------------------------------- collide (core/world.py:264-310)
 
-__device__ inline void collide(Env& e, const int8_t* grid_s, double& px, double& py, double& pz) {
+__device__ inline void collide(Env& e, const uint32_t* grid_s, double& px, double& py, double& pz) {
     const int nx = (int)__builtin_rint(px), ny = (int)__builtin_rint(py), nz = (int)__builtin_rint(pz);
     double d;
     // face (0, 1, 0)
@@ -264,54 +275,71 @@ __device__ inline void collide(Env& e, const int8_t* grid_s, double& px, double&
 
 struct Hit {
     bool hit, have_prev;
-    int bx, by, bz, colour;
-    int px, py, pz;
+    int bx, by, bz;  // the block that was hit (ground when by == -2)
+    int px, py, pz;  // `previous`: the last empty cell in front of it
 };
 
 // Sample k is position + k sequential additions of vector/5 (the reference's recurrence, so the
 // rounding of every partial sum is reproduced); lane j of the group evaluates samples j, j+GS, ...
 // and a group ballot picks the first `key != previous and key in world`.
 template <int GS>
-__device__ inline Hit hit_test(const Grp<GS>& G, const int8_t* grid_s, double x, double y, double z,
+__device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x, double y, double z,
                                double vx, double vy, double vz) {
     constexpr int SAMPLES = 40;  // max_distance 8 * m 5
-    constexpr int ROUNDS = (SAMPLES + GS - 1) / GS;
     const double sx = vx / 5.0, sy = vy / 5.0, sz = vz / 5.0;
     Hit h;
     h.hit = false; h.have_prev = false;
-    h.bx = h.by = h.bz = h.colour = 0;
+    h.bx = h.by = h.bz = 0;
     h.px = h.py = h.pz = 0;
-    int lkx = 0, lky = 0, lkz = 0;  // key of the last sample of the previous round
+    if constexpr (GS == 1) {
+        // one lane per env: the reference loop as is; stop when every active lane has its answer
+        int qx = 0, qy = 0, qz = 0;
+        for (int s = 0; s < SAMPLES; s++) {
+            const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
+            const bool differs = (s == 0) || kx != qx || ky != qy || kz != qz;
+            if (!h.hit && differs && world_has(occ_s, kx, ky, kz)) {
+                h.hit = true;
+                h.have_prev = s != 0;
+                h.bx = kx; h.by = ky; h.bz = kz;
+                h.px = qx; h.py = qy; h.pz = qz;
+            }
+            if (!__any(!h.hit)) break;
+            qx = kx; qy = ky; qz = kz;
+            x = x + sx; y = y + sy; z = z + sz;
+        }
+        return h;
+    } else {
+        constexpr int ROUNDS = (SAMPLES + GS - 1) / GS;
+        int lkx = 0, lky = 0, lkz = 0;  // key of the last sample of the previous round
 #pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        const int s = r * GS + G.gl;
-        int nadd = (r == 0) ? G.gl : GS;
-        if (GS == 64) nadd = min(nadd, SAMPLES - 1);
-        const int bound = (r == 0) ? min(GS - 1, SAMPLES - 1) : GS;
-        for (int i = 0; i < bound; i++) {
-            if (i < nadd) { x = x + sx; y = y + sy; z = z + sz; }
+        for (int r = 0; r < ROUNDS; r++) {
+            const int s = r * GS + G.gl;
+            int nadd = (r == 0) ? G.gl : GS;
+            if (GS == 64) nadd = min(nadd, SAMPLES - 1);
+            const int bound = (r == 0) ? min(GS - 1, SAMPLES - 1) : GS;
+            for (int i = 0; i < bound; i++) {
+                if (i < nadd) { x = x + sx; y = y + sy; z = z + sz; }
+            }
+            const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
+            int qx = G.shfl_up1(kx), qy = G.shfl_up1(ky), qz = G.shfl_up1(kz);
+            if (G.gl == 0) { qx = lkx; qy = lky; qz = lkz; }
+            const bool differs = (s == 0) || kx != qx || ky != qy || kz != qz;
+            const bool inw = world_has(occ_s, kx, ky, kz);
+            const bool cand = !h.hit && s < SAMPLES && differs && inw;
+            const uint64_t m = G.ballot(cand);
+            if (m != 0 && !h.hit) {
+                const int first = __builtin_ctzll(m);
+                h.hit = true;
+                h.have_prev = !(r == 0 && first == 0);
+                h.bx = G.bcast(kx, first); h.by = G.bcast(ky, first); h.bz = G.bcast(kz, first);
+                h.px = G.bcast(qx, first); h.py = G.bcast(qy, first); h.pz = G.bcast(qz, first);
+            }
+            if (r + 1 < ROUNDS) {
+                lkx = G.bcast(kx, GS - 1); lky = G.bcast(ky, GS - 1); lkz = G.bcast(kz, GS - 1);
+            }
         }
-        const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
-        int qx = G.shfl_up1(kx), qy = G.shfl_up1(ky), qz = G.shfl_up1(kz);
-        if (G.gl == 0) { qx = lkx; qy = lky; qz = lkz; }
-        const bool differs = (s == 0) || kx != qx || ky != qy || kz != qz;
-        int col = 0;
-        const bool inw = world_lookup(grid_s, kx, ky, kz, col);
-        const bool cand = !h.hit && s < SAMPLES && differs && inw;
-        const uint64_t m = G.ballot(cand);
-        if (m != 0 && !h.hit) {
-            const int first = __builtin_ctzll(m);
-            h.hit = true;
-            h.have_prev = !(r == 0 && first == 0);
-            h.bx = G.bcast(kx, first); h.by = G.bcast(ky, first); h.bz = G.bcast(kz, first);
-            h.colour = G.bcast(col, first);
-            h.px = G.bcast(qx, first); h.py = G.bcast(qy, first); h.pz = G.bcast(qz, first);
-        }
-        if (r + 1 < ROUNDS) {
-            lkx = G.bcast(kx, GS - 1); lky = G.bcast(ky, GS - 1); lkz = G.bcast(kz, GS - 1);
-        }
+        return h;
     }
-    return h;
 }
 
 // ---------------------------------------------------------------- maximal_intersection
@@ -324,7 +352,7 @@ struct MiResult {
     int arg_dx, arg_dz, arg_rot;
 };
 
-// Whole wave, one env.  grid_s: LDS grid of the env; start_g: global starting grid row or nullptr
+// Whole wave, one env.  grid_s: LDS copy of the env's int8 grid row; start_g: global starting grid row or nullptr
 // (grid values are compared as grid - start); tgt_s: LDS copy of the target row (rotation 0);
 // hist: HIST_PAD words of LDS; bbox: 4 x (xmin, xmax, zmin, zmax) packed one int per rotation.
 template <bool ARGMAX>
@@ -436,11 +464,14 @@ __device__ inline void row_to_lds_wave(int8_t* dst_s, const int8_t* src_g) {
     uint4* d = reinterpret_cast<uint4*>(dst_s);
     for (int c = lane; c < CHUNKS; c += WAVE) d[c] = s[c];
 }
-template <int GS>
-__device__ inline void row_to_lds_group(int gl, int8_t* dst_s, const int8_t* src_g) {
-    const uint4* s = reinterpret_cast<const uint4*>(src_g);
-    uint4* d = reinterpret_cast<uint4*>(dst_s);
-    for (int c = gl; c < CHUNKS; c += GS) d[c] = s[c];
+// same, bypassing this CU's vector L1 (agent-scope relaxed loads): used where the kernel itself wrote
+// bytes of the row earlier in the launch (fused rollout)
+__device__ inline void row_to_lds_wave_coherent(int8_t* dst_s, const int8_t* src_g) {
+    const int lane = __lane_id();
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src_g);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst_s);
+    for (int c = lane; c < STRIDE / 4; c += WAVE)
+        d[c] = __hip_atomic_load(s + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace igw

@@ -36,35 +36,17 @@ struct StepOut {
     bool done;
 };
 
-struct TaskView {  // per-group view of the env's task row (uniform in the group)
-    int task;
-    int target_size, env_max_int;
-    bool has_start;
-};
-
 __device__ inline void stat_add(unsigned long long* stats, int which, unsigned long long v) {
     if (stats) atomicAdd(&stats[(blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + which], v);
 }
 
-// GridWorld.reset (env.py:206-261) for one env, executed by its lane group.  `grid_g` is the env's
-// HBM row, `grid_s` its LDS copy (may be nullptr when the kernel ends right after).
-template <int GS>
-__device__ inline void reset_env(const Grp<GS>& G, const KParams& p, Env& e, const TaskMeta* meta,
-                                 const int8_t* start_row, bool has_start, int8_t* grid_g, int8_t* grid_s,
-                                 bool keep_size) {
+// per-lane part of GridWorld.reset (env.py:206-261): everything except the grid / bitmap rows
+__device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_size) {
     if (!keep_size) e.size = 0;  // SizeReward.reset, env.py:321-323
     e.step_no = 0;               // env.py:217
     e.prev_size = 0;             // _synthetic_task.reset(): prev_grid_size = 0, max_int = 0 (task.py:74-86)
     e.max_int = 0;
-    uint4* dg = reinterpret_cast<uint4*>(grid_g);
-    uint4* ds = reinterpret_cast<uint4*>(grid_s);
-    const uint4* src = reinterpret_cast<const uint4*>(start_row);
-    for (int c = G.gl; c < CHUNKS; c += GS) {  // env.py:234-238: world := starting grid
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (has_start) v = src[c];
-        dg[c] = v;
-        if (grid_s) ds[c] = v;
-    }
+    e.target_size = meta->target_size;
     e.x = meta->pose[0]; e.y = meta->pose[1]; e.z = meta->pose[2];  // env.py:239-240
     e.yaw = meta->pose[3]; e.pitch = meta->pose[4];
     uint64_t inv = 0;  // env.py:243-246
@@ -72,6 +54,20 @@ __device__ inline void reset_env(const Grp<GS>& G, const KParams& p, Env& e, con
     for (int i = 0; i < 6; i++) inv |= (uint64_t)(uint8_t)meta->inv_init[i] << (8 * i);
     e.inv = inv;
     // agent.dy, time_int_steps, active_block are NOT reset by the reference
+}
+
+// whole-wave copy of the starting grid and its occupancy bitmap into one env's rows
+// (env.py:234-238: world := starting grid); occ_s may be nullptr when the kernel ends right after
+__device__ inline void reset_rows_wave(const KParams& p, int env, int task, bool has_start, uint32_t* occ_s) {
+    const int lane = __lane_id();
+    uint4* dg = reinterpret_cast<uint4*>(p.grid + (size_t)env * STRIDE);
+    const uint4* sg = reinterpret_cast<const uint4*>(p.task_start + (size_t)task * STRIDE);
+    for (int c = lane; c < CHUNKS; c += WAVE) dg[c] = has_start ? sg[c] : make_uint4(0, 0, 0, 0);
+    if (lane < OCC_WORDS) {
+        const uint32_t v = has_start ? p.task_start_occ[(size_t)task * OCC_WORDS + lane] : 0u;
+        p.occ[(size_t)env * OCC_WORDS + lane] = v;
+        if (occ_s) occ_s[lane] = v;
+    }
 }
 
 // obs of reset(): agentPos zeros, compass 0 (env.py:247-254)
@@ -102,9 +98,9 @@ struct CellChange {
 // World.step (core/world.py:434-456) after action parsing, for one env; every lane of the group runs
 // it with identical inputs, hit_test splits its samples over the lanes.
 template <int GS, int MODE>
-__device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env& e, int8_t* grid_s,
-                                        const TrigCtx& trig, double s0, double s1, double dy, int inventory,
-                                        double cam0, double cam1, bool remove, bool add) {
+__device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
+                                        const int8_t* grid_g, const TrigCtx& trig, double s0, double s1, double dy,
+                                        int inventory, double cam0, double cam1, bool remove, bool add) {
     constexpr bool FLY = MODE == MODE_FLY;
     CellChange ch;
     ch.idx = -1; ch.old_val = 0; ch.new_val = 0;
@@ -122,12 +118,12 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
         e.pitch = y;
     }
     // place_or_remove_block, :312-332
-    if (add != remove) {
+    if (add != remove && !(p.debug & 2)) {
         double sp, cp, sy, cy;
         sincos_deg(trig, e.pitch, sp, cp);       // m = cos(radians(y)); dy = sin(radians(y))
         sincos_deg(trig, e.yaw - 90.0, sy, cy);  // dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
         const double vx = cy * cp, vy = sp, vz = sy * cp;
-        const Hit h = hit_test<GS>(G, grid_s, e.x, e.y, e.z, vx, vy, vz);
+        const Hit h = hit_test<GS>(G, occ_s, e.x, e.y, e.z, vx, vy, vz);
         if (add) {
             if (h.hit && h.have_prev) {
                 if (inv_get(e.inv, e.active - 1) > 0 && build_zone_i(h.px, h.py, h.pz)) {
@@ -145,18 +141,24 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
                 }
             }
         }
-        if (remove && h.hit) {
-            const int texture = h.colour;
-            if (texture != 0 && texture != -1) {  // GREY / WHITE ground cannot be broken
-                ch.idx = cell_of(h.bx, h.by, h.bz);
-                ch.old_val = texture;
-                ch.new_val = 0;
-                if (texture >= 1 && texture <= 6) e.inv = inv_add(e.inv, texture - 1, 1);
-            }
+        if (remove && h.hit && h.by != -2) {  // GREY / WHITE ground cannot be broken (:330)
+            const int cell = cell_of(h.bx, h.by, h.bz);
+            // colour of the block: the one int8 the physics ever needs (L1-bypassing load: a fused
+            // rollout may have written this row earlier in the same launch)
+            const int texture = __hip_atomic_load(grid_g + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ch.idx = cell;
+            ch.old_val = texture;
+            ch.new_val = 0;
+            if (texture >= 1 && texture <= 6) e.inv = inv_add(e.inv, texture - 1, 1);
         }
         if (ch.idx >= 0) {
             wave_sync();
-            if (G.gl == 0) grid_s[ch.idx] = (int8_t)ch.new_val;
+            if (G.gl == 0) {
+                const uint32_t bit = 1u << (ch.idx & 31);
+                uint32_t w = occ_s[ch.idx >> 5];
+                w = ch.new_val ? (w | bit) : (w & ~bit);
+                occ_s[ch.idx >> 5] = w;
+            }
             wave_sync();
         }
     }
@@ -188,7 +190,7 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
                 mvz = sx;
             }
         }
-        for (int i = 0; i < m; i++) {  // _update, :222-262
+        for (int i = 0; i < ((p.debug & 4) ? 0 : m); i++) {  // _update, :222-262
             const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
             const double d = dt * speed;
             const double ddx = mvx * d, ddz = mvz * d;
@@ -204,11 +206,11 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
             ddy += e.vy * dt;
             double cx = e.x + ddx, cy = e.y + ddy, cz = e.z + ddz;
             if (build_zone_d(cx, cy, cz, 2.0)) {
-                collide(e, grid_s, cx, cy, cz);
+                collide(e, occ_s, cx, cy, cz);
                 e.x = cx; e.y = cy; e.z = cz;
             } else if (!FLY) {
                 cx = e.x; cz = e.z;
-                collide(e, grid_s, cx, cy, cz);
+                collide(e, occ_s, cx, cy, cz);
                 e.x = cx; e.y = cy; e.z = cz;
             }
         }
@@ -222,8 +224,8 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
 
 // parse_walking_discrete_action (core/world.py:360-394) + World.step
 template <int GS>
-__device__ inline CellChange step_walking_action(const Grp<GS>& G, const KParams& p, Env& e, int8_t* grid_s,
-                                                 const TrigCtx& trig, int action) {
+__device__ inline CellChange step_walking_action(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
+                                                 const int8_t* grid_g, const TrigCtx& trig, int action) {
     double s0 = 0.0, s1 = 0.0, dy = 0.0, cam0 = 0.0, cam1 = 0.0;
     int inventory = 0;
     bool remove = false, add = false;
@@ -239,7 +241,7 @@ __device__ inline CellChange step_walking_action(const Grp<GS>& G, const KParams
     else if (action == 15) cam1 = 5.0;
     else if (action == 16) remove = true;
     else if (action == 17) add = true;
-    return world_step<GS, MODE_WALK>(G, p, e, grid_s, trig, s0, s1, dy, inventory, cam0, cam1, remove, add);
+    return world_step<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, s0, s1, dy, inventory, cam0, cam1, remove, add);
 }
 
 // Task.step_intersection (tasks/task.py:103-119) part 1: block-count delta of the synthetic grid
@@ -250,9 +252,9 @@ __device__ inline int syn_size_delta(const CellChange& ch, int start_val) {
 }
 
 // part 2 + GridWorld.step tail (env.py:290-296) + SizeReward.step (env.py:325-331)
-__device__ inline StepOut finish_step(const KParams& p, Env& e, const TaskView& tv, int size_new, int mi) {
+__device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int, int size_new, int mi) {
     const int wrong = e.prev_size - size_new;
-    bool done = mi == tv.target_size;
+    bool done = mi == e.target_size;
     e.prev_size = size_new;
     const int right = mi - e.max_int;
     e.max_int = mi;
@@ -261,7 +263,7 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, const TaskView& 
     if (right == 0) reward = (double)wrong * p.wrong_scale;
     else reward = (double)right * p.right_scale;
     if (p.size_reward) {
-        const int mx = max(tv.env_max_int, e.size);
+        const int mx = max(env_max_int, e.size);
         reward = (double)(mx - e.size);
         e.size = mx;
     }
@@ -274,9 +276,11 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, const TaskView& 
 template <int GS>
 struct BlockShared {
     static constexpr int EPB = BLOCK / GS;  // envs per block
+    static constexpr int EPW = WAVE / GS;   // envs per wave
     double lut[IGW_LUT_N * 2];
-    alignas(16) int8_t grid[EPB][STRIDE];
-    alignas(16) int8_t tgt[WAVES_PER_BLOCK][STRIDE];
+    uint32_t occ[EPB * OCC_PITCH];                       // occupancy bitmaps, one per env
+    alignas(16) int8_t rowG[WAVES_PER_BLOCK][STRIDE];    // per wave: int8 grid row (reward recompute only)
+    alignas(16) int8_t rowT[WAVES_PER_BLOCK][STRIDE];    // per wave: synthetic target row
     uint32_t hist[WAVES_PER_BLOCK][HIST_PAD];
 };
 
@@ -287,10 +291,27 @@ __device__ inline void load_lut(double* lut_s) {
     __syncthreads();
 }
 
-// max_intersection for every group of this wave that asked for it, one env at a time with all 64 lanes
+// the wave's EPW contiguous bitmap rows HBM -> LDS, coalesced dwordx4, LDS pitch OCC_PITCH
 template <int GS>
-__device__ inline int resolve_max_intersection(const Grp<GS>& G, const KParams& p, BlockShared<GS>& sh,
-                                               bool need, int slot, int task, bool has_start, int mi_cached) {
+__device__ inline void load_occ_wave(const KParams& p, int first_env, uint32_t* occ_wave_s) {
+    constexpr int EPW = WAVE / GS;
+    constexpr int CH = OCC_WORDS / 4;  // 9 chunks of 16 B per env
+    const int lane = __lane_id();
+    const int valid = min(EPW, p.n_envs - first_env);
+    const uint4* src = reinterpret_cast<const uint4*>(p.occ + (size_t)first_env * OCC_WORDS);
+    for (int c = lane; c < valid * CH; c += WAVE) {
+        const uint4 v = src[c];
+        uint32_t* d = occ_wave_s + (c / CH) * OCC_PITCH + (c % CH) * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+// max_intersection for every env of this wave that asked for it, one env at a time with all 64 lanes.
+// COHERENT: the launch itself may have written bytes of the grid row earlier (fused rollout).
+template <int GS, bool COHERENT>
+__device__ inline int resolve_max_intersection(const Grp<GS>& G, const KParams& p, BlockShared<GS>& sh, bool need,
+                                               int env, int task, bool has_start, int ch_idx, int ch_val,
+                                               int mi_cached) {
     const int wave = threadIdx.x / WAVE;
     uint64_t needm = __ballot(need);
     int mi = mi_cached;
@@ -298,21 +319,46 @@ __device__ inline int resolve_max_intersection(const Grp<GS>& G, const KParams& 
         const int l = __builtin_ctzll(needm);
         const int gsel = l / GS;
         if constexpr (GS == 64) needm = 0;
+        else if constexpr (GS == 1) needm &= needm - 1;
         else needm &= ~(((1ull << GS) - 1ull) << (gsel * GS));
+        const int t_env = __builtin_amdgcn_readlane(env, l);
         const int t_task = __builtin_amdgcn_readlane(task, l);
-        const int t_slot = __builtin_amdgcn_readlane(slot, l);
         const int t_hs = __builtin_amdgcn_readlane((int)has_start, l);
+        const int t_idx = __builtin_amdgcn_readlane(ch_idx, l);
+        const int t_val = __builtin_amdgcn_readlane(ch_val, l);
         const int* bbp = reinterpret_cast<const int*>(p.task_meta[t_task].bbox);
         int bbox4[4] = {bbp[0], bbp[1], bbp[2], bbp[3]};
         wave_sync();
-        row_to_lds_wave(sh.tgt[wave], p.task_target + (size_t)t_task * STRIDE);
+        if (COHERENT) row_to_lds_wave_coherent(sh.rowG[wave], p.grid + (size_t)t_env * STRIDE);
+        else row_to_lds_wave(sh.rowG[wave], p.grid + (size_t)t_env * STRIDE);
+        row_to_lds_wave(sh.rowT[wave], p.task_target + (size_t)t_task * STRIDE);
+        wave_sync();
+        if (__lane_id() == 0) sh.rowG[wave][t_idx] = (int8_t)t_val;  // this step's change is not in HBM yet
         wave_sync();
         const MiResult r = max_intersection_wave<false>(
-            sh.grid[t_slot], t_hs ? p.task_start + (size_t)t_task * STRIDE : nullptr, sh.tgt[wave],
+            sh.rowG[wave], t_hs ? p.task_start + (size_t)t_task * STRIDE : nullptr, sh.rowT[wave],
             sh.hist[wave], bbox4, 4);
         if (G.g == gsel) mi = r.max_int;
     }
     return mi;
+}
+
+// auto-reset rows of every done env of this wave (whole wave per env, coalesced)
+template <int GS>
+__device__ inline void resolve_resets(const Grp<GS>& G, const KParams& p, bool do_reset, int env, int task,
+                                      bool has_start, uint32_t* occ_wave_s) {
+    uint64_t m = __ballot(do_reset);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        const int gsel = l / GS;
+        if constexpr (GS == 64) m = 0;
+        else if constexpr (GS == 1) m &= m - 1;
+        else m &= ~(((1ull << GS) - 1ull) << (gsel * GS));
+        const int t_env = __builtin_amdgcn_readlane(env, l);
+        const int t_task = __builtin_amdgcn_readlane(task, l);
+        const int t_hs = __builtin_amdgcn_readlane((int)has_start, l);
+        reset_rows_wave(p, t_env, t_task, t_hs != 0, occ_wave_s ? occ_wave_s + gsel * OCC_PITCH : nullptr);
+    }
 }
 
 template <int GS, int MODE>
@@ -321,56 +367,75 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     const Grp<GS> G;
     TrigCtx trig;
     trig.lut = sh.lut;
-    load_lut(sh.lut);
+    const int wave = threadIdx.x / WAVE;
     const int slot = threadIdx.x / GS;
     const int env = blockIdx.x * BlockShared<GS>::EPB + slot;
+    const int wave_env0 = blockIdx.x * BlockShared<GS>::EPB + wave * BlockShared<GS>::EPW;
     const bool active = env < p.n_envs;
-    if (GS == 64 && !active) return;
+    uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
+    uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
+    if (wave_env0 < p.n_envs) load_occ_wave<GS>(p, wave_env0, occ_wave_s);
+    load_lut(sh.lut);
+    if (wave_env0 >= p.n_envs) return;
     Env e = {};
-    TaskView tv = {};
-    const TaskMeta* meta = nullptr;
-    int8_t* grid_s = sh.grid[slot];
-    int8_t* grid_g = nullptr;
     CellChange ch;
     ch.idx = -1; ch.old_val = ch.new_val = 0;
-    int size_new = 0;
-    bool need = false;
+    int size_new = 0, task = 0, env_max_int = 0;
+    bool need = false, has_start = false;
+    const TaskMeta* meta = nullptr;
+    int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
     if (active) {
-        grid_g = p.grid + (size_t)env * STRIDE;
-        row_to_lds_group<GS>(G.gl, grid_s, grid_g);
-        tv.task = p.env_task[env];
-        meta = p.task_meta + tv.task;
-        tv.target_size = meta->target_size;
-        tv.env_max_int = meta->env_max_int;
-        tv.has_start = meta->has_start != 0;
         env_load(e, p.agent + env);
         wave_sync();
         e.step_no = min(e.step_no + 1, 65535);  // env.py:276
         if (MODE == MODE_WALK) {
-            ch = step_walking_action<GS>(G, p, e, grid_s, trig, a.actions[env]);
+            ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, a.actions[env]);
         } else {  // parse_flying_action, core/world.py:416-432
             const float* mv = a.movement + 3 * (size_t)env;
             const float* cam = a.camera + 2 * (size_t)env;
             const int placement = a.placement[env];
-            ch = world_step<GS, MODE_FLY>(G, p, e, grid_s, trig, (double)mv[0], (double)mv[1], (double)mv[2],
+            ch = world_step<GS, MODE_FLY>(G, p, e, occ_s, grid_g, trig, (double)mv[0], (double)mv[1], (double)mv[2],
                                           a.inventory[env], (double)cam[0], (double)cam[1], placement == 2,
                                           placement == 1);
         }
-        int start_val = 0;
-        if (ch.idx >= 0 && tv.has_start) start_val = p.task_start[(size_t)tv.task * STRIDE + ch.idx];
-        size_new = e.prev_size + syn_size_delta(ch, start_val);
-        need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
+        size_new = e.prev_size;
+        // the task row is only touched when the grid changed, an episode starts / ends, or SizeReward needs it
+        if (ch.idx >= 0 || (p.size_reward && e.step_no == 1)) {
+            task = p.env_task[env];
+            meta = p.task_meta + task;
+            has_start = meta->has_start != 0;
+            env_max_int = meta->env_max_int;
+            if (ch.idx >= 0) {
+                int start_val = 0;
+                if (has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
+                size_new = e.prev_size + syn_size_delta(ch, start_val);
+                need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
+                if (p.debug & 1) need = false;
+            }
+        }
     }
-    const int mi = resolve_max_intersection<GS>(G, p, sh, need, slot, tv.task, tv.has_start, e.max_int);
+    const int mi = resolve_max_intersection<GS, false>(G, p, sh, need, env, task, has_start, ch.idx, ch.new_val,
+                                                       e.max_int);
+    StepOut o;
+    o.reward = 0.0; o.done = false;
+    bool do_reset = false;
+    if (active) {
+        o = finish_step(p, e, env_max_int, size_new, mi);
+        do_reset = o.done && p.autoreset;
+        if (do_reset && meta == nullptr) {
+            task = p.env_task[env];
+            meta = p.task_meta + task;
+            has_start = meta->has_start != 0;
+        }
+    }
+    resolve_resets<GS>(G, p, do_reset, env, task, has_start, nullptr);
     if (!active) return;
-    const StepOut o = finish_step(p, e, tv, size_new, mi);
-    const bool do_reset = o.done && p.autoreset;
-    if (do_reset) {
-        reset_env<GS>(G, p, e, meta, p.task_start + (size_t)tv.task * STRIDE, tv.has_start, grid_g, nullptr,
-                      false);
-    }
+    if (do_reset) reset_env_regs(e, meta, false);
     if (G.gl == 0) {
-        if (ch.idx >= 0 && !do_reset) grid_g[ch.idx] = (int8_t)ch.new_val;
+        if (ch.idx >= 0 && !do_reset) {
+            grid_g[ch.idx] = (int8_t)ch.new_val;
+            p.occ[(size_t)env * OCC_WORDS + (ch.idx >> 5)] = occ_s[ch.idx >> 5];
+        }
         p.reward[env] = (float)o.reward;
         p.done[env] = o.done ? 1 : 0;
         if (do_reset) write_reset_obs(p, env, e);
@@ -389,25 +454,27 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
     const Grp<GS> G;
     TrigCtx trig;
     trig.lut = sh.lut;
-    load_lut(sh.lut);
+    const int wave = threadIdx.x / WAVE;
     const int slot = threadIdx.x / GS;
     const int env = blockIdx.x * BlockShared<GS>::EPB + slot;
+    const int wave_env0 = blockIdx.x * BlockShared<GS>::EPB + wave * BlockShared<GS>::EPW;
     const bool active = env < p.n_envs;
-    if (GS == 64 && !active) return;
+    uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
+    uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
+    if (wave_env0 < p.n_envs) load_occ_wave<GS>(p, wave_env0, occ_wave_s);
+    load_lut(sh.lut);
+    if (wave_env0 >= p.n_envs) return;
     Env e = {};
-    TaskView tv = {};
+    int task = 0, env_max_int = 0;
+    bool has_start = false;
     const TaskMeta* meta = nullptr;
-    int8_t* grid_s = sh.grid[slot];
-    int8_t* grid_g = nullptr;
+    int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
     if (active) {
-        grid_g = p.grid + (size_t)env * STRIDE;
-        row_to_lds_group<GS>(G.gl, grid_s, grid_g);
-        tv.task = p.env_task[env];
-        meta = p.task_meta + tv.task;
-        tv.target_size = meta->target_size;
-        tv.env_max_int = meta->env_max_int;
-        tv.has_start = meta->has_start != 0;
         env_load(e, p.agent + env);
+        task = p.env_task[env];
+        meta = p.task_meta + task;
+        has_start = meta->has_start != 0;
+        env_max_int = meta->env_max_int;
     }
     wave_sync();
     unsigned long long n_changed = 0, n_resets = 0;
@@ -422,33 +489,34 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
         if (active) {
             e.step_no = min(e.step_no + 1, 65535);
             const int action = rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
-            ch = step_walking_action<GS>(G, p, e, grid_s, trig, action);
+            ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, action);
             int start_val = 0;
-            if (ch.idx >= 0 && tv.has_start) start_val = p.task_start[(size_t)tv.task * STRIDE + ch.idx];
+            if (ch.idx >= 0 && has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
             size_new = e.prev_size + syn_size_delta(ch, start_val);
             need = size_new != e.prev_size;
         }
-        const int mi = resolve_max_intersection<GS>(G, p, sh, need, slot, tv.task, tv.has_start, e.max_int);
+        const int mi = resolve_max_intersection<GS, true>(G, p, sh, need, env, task, has_start, ch.idx, ch.new_val,
+                                                          e.max_int);
+        bool do_reset = false;
         if (active) {
-            o = finish_step(p, e, tv, size_new, mi);
+            o = finish_step(p, e, env_max_int, size_new, mi);
             n_changed += need;
-            last_reset = o.done;
-            if (o.done) {
-                wave_sync();
-                reset_env<GS>(G, p, e, meta, p.task_start + (size_t)tv.task * STRIDE, tv.has_start, grid_g,
-                              grid_s, false);
-                wave_sync();
-                n_resets++;
-            }
+            do_reset = o.done;
+            last_reset = do_reset;
+            // colours go to HBM right away (a later break / reward recompute of this launch reads them)
+            if (ch.idx >= 0 && !do_reset && G.gl == 0) grid_g[ch.idx] = (int8_t)ch.new_val;
+        }
+        wave_sync();
+        resolve_resets<GS>(G, p, do_reset, env, task, has_start, occ_wave_s);
+        wave_sync();
+        if (active && do_reset) {
+            reset_env_regs(e, meta, false);
+            n_resets++;
         }
     }
     if (!active) return;
     wave_sync();
-    {  // grid row back to HBM
-        const uint4* s = reinterpret_cast<const uint4*>(grid_s);
-        uint4* d = reinterpret_cast<uint4*>(grid_g);
-        for (int c = G.gl; c < CHUNKS; c += GS) d[c] = s[c];
-    }
+    for (int w = G.gl; w < OCC_WORDS; w += GS) p.occ[(size_t)env * OCC_WORDS + w] = occ_s[w];
     if (G.gl == 0) {
         p.reward[env] = (float)o.reward;
         p.done[env] = o.done ? 1 : 0;
@@ -461,20 +529,18 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
     }
 }
 
-template <int GS>
+// GridWorld.reset for the masked envs: one wavefront per env (rows move coalesced)
 __global__ __launch_bounds__(BLOCK) void reset_kernel(KParams p, const uint8_t* mask, int keep_size) {
-    const Grp<GS> G;
-    const int slot = threadIdx.x / GS;
-    const int env = blockIdx.x * (BLOCK / GS) + slot;
+    const int env = blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE;
     if (env >= p.n_envs) return;
     if (mask && !mask[env]) return;
     Env e;
     env_load(e, p.agent + env);
     const int task = p.env_task[env];
     const TaskMeta* meta = p.task_meta + task;
-    reset_env<GS>(G, p, e, meta, p.task_start + (size_t)task * STRIDE, meta->has_start != 0,
-                  p.grid + (size_t)env * STRIDE, nullptr, keep_size != 0);
-    if (G.gl == 0) {
+    reset_rows_wave(p, env, task, meta->has_start != 0, nullptr);
+    reset_env_regs(e, meta, keep_size != 0);
+    if (__lane_id() == 0) {
         write_reset_obs(p, env, e);
         p.reward[env] = 0.f;
         p.done[env] = 0;
@@ -591,6 +657,15 @@ __global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int fir
         const uint4* s = reinterpret_cast<const uint4*>(S);
         uint4* d = reinterpret_cast<uint4*>(const_cast<int8_t*>(p.task_start) + (size_t)task * STRIDE);
         for (int c = lane; c < CHUNKS; c += WAVE) d[c] = s[c];
+        // occupancy bitmap of the starting grid: lane w packs cells 32w .. 32w+31
+        if (lane < OCC_WORDS) {
+            uint32_t bits = 0;
+            for (int k = 0; k < 32; k++) {
+                const int c = lane * 32 + k;
+                if (c < CELLS && S[c] != 0) bits |= 1u << k;
+            }
+            const_cast<uint32_t*>(p.task_start_occ)[(size_t)task * OCC_WORDS + lane] = bits;
+        }
     }
     // synthetic target = target - starting grid (env.py:227-231), always invariant, no full grid
     wave_sync();
@@ -725,7 +800,8 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     if (cfg->action_space != IGW_WALKING_DISCRETE && cfg->action_space != IGW_FLYING)
         return fail(IGW_ERR_INVALID, "igw_create: unknown action_space");
     int gs = cfg->lanes_per_env ? cfg->lanes_per_env : 64;
-    if (gs != 64 && gs != 32 && gs != 16 && gs != 8) return fail(IGW_ERR_INVALID, "igw_create: lanes_per_env must be 0, 64, 32, 16 or 8");
+    if (gs != 64 && gs != 32 && gs != 16 && gs != 8 && gs != 4 && gs != 2 && gs != 1)
+        return fail(IGW_ERR_INVALID, "igw_create: lanes_per_env must be 0 or a power of two in 1..64");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
         return fail(IGW_ERR_NO_DEVICE, "igw_create: no HIP device available (the HIP path has no CPU fallback)");
@@ -741,6 +817,7 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     c->kp.size_reward = cfg->size_reward;
     c->kp.max_steps = cfg->max_steps;
     c->kp.autoreset = cfg->autoreset;
+    c->kp.debug = cfg->reserved;
     c->kp.right_scale = cfg->right_placement_scale;
     c->kp.wrong_scale = cfg->wrong_placement_scale;
     {
@@ -760,14 +837,16 @@ int igw_destroy(igw_ctx* ctx) {
 
 int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
     if (!ctx || !b) return fail(IGW_ERR_INVALID, "igw_bind_buffers: null argument");
-    if (!b->grid || !b->agent || !b->env_task || !b->task_target || !b->task_start || !b->task_meta ||
-        !b->agent_pos || !b->inventory || !b->compass || !b->reward || !b->done)
+    if (!b->grid || !b->occ || !b->agent || !b->env_task || !b->task_target || !b->task_start ||
+        !b->task_start_occ || !b->task_meta || !b->agent_pos || !b->inventory || !b->compass || !b->reward || !b->done)
         return fail(IGW_ERR_INVALID, "igw_bind_buffers: a required buffer is null");
-    if (((uintptr_t)b->grid | (uintptr_t)b->agent | (uintptr_t)b->task_target | (uintptr_t)b->task_start |
-         (uintptr_t)b->task_meta) & 15)
-        return fail(IGW_ERR_INVALID, "igw_bind_buffers: grid / agent / task buffers must be 16-byte aligned");
+    if (((uintptr_t)b->grid | (uintptr_t)b->occ | (uintptr_t)b->agent | (uintptr_t)b->task_target |
+         (uintptr_t)b->task_start | (uintptr_t)b->task_start_occ | (uintptr_t)b->task_meta) & 15)
+        return fail(IGW_ERR_INVALID, "igw_bind_buffers: grid / occ / agent / task buffers must be 16-byte aligned");
     KParams& k = ctx->kp;
     k.grid = b->grid;
+    k.occ = b->occ;
+    k.task_start_occ = b->task_start_occ;
     k.agent = reinterpret_cast<AgentRec*>(b->agent);
     k.env_task = b->env_task;
     k.task_target = b->task_target;
@@ -795,7 +874,10 @@ int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
         case 64: { constexpr int GS = 64; CALL; } break; \
         case 32: { constexpr int GS = 32; CALL; } break; \
         case 16: { constexpr int GS = 16; CALL; } break; \
-        default: { constexpr int GS = 8; CALL; } break;  \
+        case 8: { constexpr int GS = 8; CALL; } break;   \
+        case 4: { constexpr int GS = 4; CALL; } break;   \
+        case 2: { constexpr int GS = 2; CALL; } break;   \
+        default: { constexpr int GS = 1; CALL; } break;  \
     }
 
 static inline int env_blocks(const igw_ctx* ctx) {
@@ -819,8 +901,8 @@ int igw_prepare_tasks(igw_ctx* ctx, int32_t first, int32_t n, const int8_t* user
 int igw_reset(igw_ctx* ctx, const uint8_t* mask, int32_t flags, void* stream) {
     CHECK_CTX("igw_reset");
     const int keep = (flags & IGW_RESET_KEEP_SIZE) ? 1 : 0;
-    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(reset_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
-                                            (hipStream_t)stream, ctx->kp, mask, keep));
+    const int blocks = (ctx->cfg.num_envs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, ctx->kp, mask, keep);
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }

@@ -35,7 +35,7 @@ class VecGridWorld:
 
     def __init__(self, num_envs, device='cuda:0', action_space='walking', select_and_place=True,
                  size_reward=True, max_steps=250, right_placement_scale=1., wrong_placement_scale=0.1,
-                 discretize=True, autoreset=False, num_tasks=None, lanes_per_env=0, **ignored):
+                 discretize=True, autoreset=False, num_tasks=None, lanes_per_env=0, debug_flags=0, **ignored):
         if not torch.cuda.is_available():
             raise L.IgwError('VecGridWorld needs a HIP device (no CPU fallback)')
         if action_space not in ('walking', 'flying'):
@@ -52,10 +52,12 @@ class VecGridWorld:
         N, T, dev = self.num_envs, self.num_tasks, self.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         self.grid_buf = z((N, L.GRID_STRIDE), torch.int8)
+        self.occ_buf = z((N, L.OCC_WORDS), torch.int32)
         self.agent_buf = z((N, L.AGENT_BYTES), torch.uint8)
         self.env_task = z((N,), torch.int32)
         self.task_target = z((T, L.GRID_STRIDE), torch.int8)
         self.task_start = z((T, L.GRID_STRIDE), torch.int8)
+        self.task_start_occ = z((T, L.OCC_WORDS), torch.int32)
         self.task_meta = z((T, L.TASK_META_BYTES), torch.uint8)
         self.agent_pos = z((N, 5), torch.float32)
         self.inventory = z((N, 6), torch.float32)
@@ -65,16 +67,17 @@ class VecGridWorld:
         self.stats_buf = z((L.STAT_STRIPES, 8), torch.int64)
         # Agent.__init__ (core/world.py:12-29): time_int_steps = 2, active_block = BLUE, inventory 20
         self.agent_buf[:, 56:62] = 20
-        self.agent_buf[:, 62] = 2
-        self.agent_buf[:, 63] = 1
+        self.agent_buf[:, 62] = 1 << 2  # u16 pack: time_int_steps code 0 (= 2), active_block 1, target_size 0
         self.cfg = L.Config(dev.index or 0, N, T, L.FLYING if self.flying else L.WALKING_DISCRETE,
                             int(select_and_place), int(size_reward), self.max_steps, int(autoreset),
-                            float(right_placement_scale), float(wrong_placement_scale), int(lanes_per_env), 0)
+                            float(right_placement_scale), float(wrong_placement_scale), int(lanes_per_env),
+                            int(debug_flags))
         self.ctx = C.c_void_p()
         L.check(self.lib.igw_create(C.byref(self.cfg), C.byref(self.ctx)), 'igw_create')
-        b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.agent_buf, self.env_task, self.task_target,
-                                                self.task_start, self.task_meta, self.agent_pos, self.inventory,
-                                                self.compass, self.reward, self.done, self.stats_buf)])
+        b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.occ_buf, self.agent_buf, self.env_task,
+                                                self.task_target, self.task_start, self.task_start_occ, self.task_meta,
+                                                self.agent_pos, self.inventory, self.compass, self.reward, self.done,
+                                                self.stats_buf)])
         L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(b)), 'igw_bind_buffers')
         self.grid = torch.as_strided(self.grid_buf, (N, 9, 11, 11), (L.GRID_STRIDE, 121, 11, 1))
         self.user_target = None
@@ -187,8 +190,9 @@ class VecGridWorld:
         raw = self.agent_buf.cpu().numpy()
         out = np.zeros((self.num_envs, 8), np.float64)
         out[:, :6] = raw[:, :48].copy().view(np.float64)
-        out[:, 6] = raw[:, 62]
-        out[:, 7] = raw[:, 63]
+        pack = raw[:, 62:64].copy().view(np.uint16)[:, 0].astype(np.int64)
+        out[:, 6] = np.array([2, 4, 8, 12])[pack & 3]
+        out[:, 7] = (pack >> 2) & 7
         return out
 
     def task_state(self):

@@ -43,6 +43,9 @@ extern "C" {
 /* row stride of every [*, 9,11,11] int8 buffer: 1089 padded to a multiple of 16 B so a
  * wavefront moves one env's grid with 69 aligned dwordx4 accesses; pad bytes stay 0 */
 #define IGW_GRID_STRIDE 1104
+/* occupancy bitmap of the 1089 cells (bit = cell index), 36 dwords = 144 B per env: the per-step
+ * working set of the physics; kept in sync with `grid` by every kernel */
+#define IGW_OCC_WORDS 36
 /* bytes of per-env agent state and of per-task metadata (layouts below) */
 #define IGW_AGENT_BYTES 64
 #define IGW_TASK_META_BYTES 128
@@ -77,8 +80,8 @@ typedef struct igw_config {
     int32_t autoreset;         /* 0: caller resets on done (reference loop); 1: reset inside step */
     double right_placement_scale; /* env.py:335 */
     double wrong_placement_scale; /* env.py:337 */
-    int32_t lanes_per_env;     /* 0 = library default; 64/32/16/8: wavefront lanes cooperating on one env */
-    int32_t reserved;
+    int32_t lanes_per_env;     /* 0 = library default; 64,32,...,1: wavefront lanes cooperating on one env */
+    int32_t reserved;          /* must be 0 (timing-only ablation switches for profiling) */
 } igw_config;
 
 /*
@@ -93,8 +96,11 @@ typedef struct igw_config {
  *   52 i16 prev_size      _synthetic_task.prev_grid_size
  *   54 i16 max_int        _synthetic_task.max_int
  *   56 i8  inventory[6]   agent.inventory
- *   62 u8  time_int_steps agent.time_int_steps (leaks through reset)
- *   63 u8  active_block   agent.active_block   (leaks through reset)
+ *   62 u16 pack           bits 0-1 agent.time_int_steps code (0,1,2,3 = 2,4,8,12), bits 2-4
+ *                         agent.active_block (both leak through reset), bits 5-15 target_size of the
+ *                         synthetic task (copied from the task table by reset, so a step needs no
+ *                         task-table access unless the grid changed)
+ * A fresh agent (Agent.__init__) is inventory 20 x 6, pack = 1 << 2 (time_int_steps 2, BLUE).
  *
  * Task metadata, IGW_TASK_META_BYTES per task (written by igw_prepare_tasks):
  *   0  f64 init_pose[5]   x, y, z, yaw, pitch (GridWorld.initial_position/rotation)
@@ -107,12 +113,14 @@ typedef struct igw_config {
  */
 typedef struct igw_buffers {
     /* state */
-    int8_t* grid;          /* [N][IGW_GRID_STRIDE]   world grid == obs 'grid' */
+    int8_t* grid;          /* [N][IGW_GRID_STRIDE]   world grid (colours) == obs 'grid' */
+    uint32_t* occ;         /* [N][IGW_OCC_WORDS]     occupancy bitmap of grid */
     void* agent;           /* [N][IGW_AGENT_BYTES] */
     int32_t* env_task;     /* [N] index into the task table */
     /* task table */
     int8_t* task_target;   /* [T][IGW_GRID_STRIDE] synthetic target = target - start (env.py:230) */
     int8_t* task_start;    /* [T][IGW_GRID_STRIDE] dense starting grid (env.py:226) */
+    uint32_t* task_start_occ; /* [T][IGW_OCC_WORDS] its occupancy bitmap */
     void* task_meta;       /* [T][IGW_TASK_META_BYTES] */
     /* per-step outputs (env.py:281-303) */
     float* agent_pos;      /* [N][5] x, y, z, pitch, yaw */

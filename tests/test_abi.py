@@ -31,11 +31,11 @@ def test_layout_constants_match_header():
     src = open(os.path.join(ROOT, 'include', 'igw.h')).read()
     for name, val in (('IGW_GRID_STRIDE', _lib.GRID_STRIDE), ('IGW_CELLS', _lib.CELLS),
                       ('IGW_AGENT_BYTES', _lib.AGENT_BYTES), ('IGW_TASK_META_BYTES', _lib.TASK_META_BYTES),
-                      ('IGW_STAT_STRIPES', _lib.STAT_STRIPES)):
+                      ('IGW_STAT_STRIPES', _lib.STAT_STRIPES), ('IGW_OCC_WORDS', _lib.OCC_WORDS)):
         m = re.search(r'#define\s+%s\s+(\d+)' % name, src)
         assert m and int(m.group(1)) == val, name
     assert ctypes.sizeof(_lib.Config) == 56
-    assert ctypes.sizeof(_lib.Buffers) == 12 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.Buffers) == 14 * ctypes.sizeof(ctypes.c_void_p)
 
 
 def test_fails_loudly_without_device():

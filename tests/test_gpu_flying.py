@@ -34,7 +34,7 @@ def _fly_actions(rng, n):
                 inventory=rng.randint(7, size=n).astype(np.int32), placement=rng.randint(3, size=n).astype(np.int32))
 
 
-@pytest.mark.parametrize('gs', [64, 16])
+@pytest.mark.parametrize('gs', [64, 16, 2, 1])
 def test_flying_vs_oracle_device_trig(gs):
     from gridworld_amd import VecGridWorld, workloads
     from oracle import oracle as O

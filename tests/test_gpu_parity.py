@@ -21,8 +21,8 @@ def test_walking_fixture(name):
     assert GR.replay(fx, _hip(fx)) == fx['done'].size
 
 
-@pytest.mark.parametrize('gs', [32, 16, 8])
-@pytest.mark.parametrize('name', ['s2_walk_cdm', 's3_walk_rt20', 's5_scripted'])
+@pytest.mark.parametrize('gs', [64, 32, 16, 8, 4, 2, 1])
+@pytest.mark.parametrize('name', ['s2_walk_cdm', 's3_walk_rt20', 's5_scripted', 's5_init_pose'])
 def test_walking_fixture_lane_groups(name, gs):
     fx = GR.load_fixture(name)
     GR.replay(fx, _hip(fx, lanes_per_env=gs), max_steps=260)
@@ -82,7 +82,7 @@ def _compare(env, ob, where):
     assert np.array_equal(env.compass.cpu().numpy().view(np.uint32), ob.compass.view(np.uint32)), where + ' compass'
 
 
-@pytest.mark.parametrize('gs', [64, 16])
+@pytest.mark.parametrize('gs', [64, 16, 4, 1])
 def test_config2_4096_envs_vs_oracle(gs):
     """BASELINE config 2: 4,096 parallel envs, walking, DUMMY-equivalent task, bit-exact vs the CPU
     path on counter-RNG action streams, auto-reset inside step (max_steps=50 so resets happen)."""
@@ -108,14 +108,16 @@ def test_config2_4096_envs_vs_oracle(gs):
     assert env.stats()['resets'] == n * (T // 50)
 
 
-def test_rt20_autoreset_vs_oracle():
-    """rt20 targets (full maximal_intersection reward), 1,024 envs, per-env tasks, vs the oracle."""
+@pytest.mark.parametrize('gs', [0, 8, 2, 1])
+def test_rt20_autoreset_vs_oracle(gs):
+    """rt20 targets (full maximal_intersection reward), 1,000 envs (ragged last block), per-env tasks,
+    vs the oracle; the occupancy bitmap must stay in sync with the int8 grid."""
     from gridworld_amd import VecGridWorld
     from oracle import oracle as O
-    n, T = 1024, 300
+    n, T = 1000, 300
     kw = dict(size_reward=False)
     tg = _rt20_targets(n, 5)
-    env = VecGridWorld(n, autoreset=True, **kw)
+    env = VecGridWorld(n, autoreset=True, lanes_per_env=gs, **kw)
     env.set_tasks(tg)
     env.reset()
     ob = O.OracleBatch(n, **kw)
@@ -131,16 +133,28 @@ def test_rt20_autoreset_vs_oracle():
             _compare(env, ob, f'step {t}')
     st = env.stats()
     assert st['resets'] >= n and 0.01 < st['changed'] / (n * T) < 0.3
+    _check_occ(env)
 
 
-def test_fused_rollout_vs_oracle():
+def _check_occ(env):
+    torch.cuda.synchronize()
+    g = env.grid.cpu().numpy().reshape(env.num_envs, -1) != 0
+    bits = np.zeros((env.num_envs, 36 * 32), bool)
+    bits[:, :1089] = g
+    want = np.packbits(bits.reshape(env.num_envs, 36, 32), axis=-1, bitorder='little').view(np.uint32)[:, :, 0]
+    got = env.occ_buf.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, want), 'occupancy bitmap out of sync with the grid'
+
+
+@pytest.mark.parametrize('gs', [0, 16, 1])
+def test_fused_rollout_vs_oracle(gs):
     """igw_rollout_walking (T steps in one launch, counter RNG, auto-reset) == T single steps == oracle."""
     from gridworld_amd import VecGridWorld
     from oracle import oracle as O
-    n, T = 512, 300
+    n, T = 500, 300
     kw = dict(size_reward=False)
     tg = _rt20_targets(n, 11)
-    env = VecGridWorld(n, autoreset=True, **kw)
+    env = VecGridWorld(n, autoreset=True, lanes_per_env=gs, **kw)
     env.set_tasks(tg)
     env.reset()
     env.rollout(T, seed=4242)
@@ -162,6 +176,8 @@ def test_fused_rollout_vs_oracle():
         env2.step(acts[t])
     torch.cuda.synchronize()
     assert torch.equal(env.grid_buf, env2.grid_buf) and torch.equal(env.agent_buf, env2.agent_buf)
+    assert torch.equal(env.occ_buf, env2.occ_buf)
+    _check_occ(env)
 
 
 def test_product_does_not_import_oracle():
