@@ -14,8 +14,9 @@ CELLS = 1089
 AGENT_BYTES = 64
 TASK_META_BYTES = 128
 OCC_WORDS = 36
+HIST_ROW = 512
 STAT_STRIPES = 64
-STAT_CHANGED, STAT_RESETS, STAT_STEPS = 0, 1, 2
+STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS = 0, 1, 2, 3
 WALKING_DISCRETE, FLYING = 0, 1
 RESET_KEEP_SIZE = 1
 
@@ -38,7 +39,7 @@ class Config(C.Structure):
 
 
 class Buffers(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('grid', 'occ', 'agent', 'env_task', 'task_target', 'task_start',
+    _fields_ = [(n, C.c_void_p) for n in ('grid', 'occ', 'hist', 'agent', 'env_task', 'task_target', 'task_start',
                                           'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass',
                                           'reward', 'done', 'stats')]
 

@@ -34,6 +34,7 @@ constexpr int HIST_PAD = 256;
 // occupancy bitmap of the 1089 cells (bit = cell index): the per-step working set of the physics
 constexpr int OCC_WORDS = IGW_OCC_WORDS;  // 36 dwords = 144 B per env in HBM
 constexpr int OCC_PITCH = 37;             // LDS pitch (odd => conflict-free when one lane owns one env)
+constexpr int HIST_ROW = IGW_HIST_ROW;    // persistent per-env vote histogram: 512 x u16 (484 used)
 
 // gridworld/utils.py:9-24 and core/world.py:9
 constexpr double WALKING_SPEED = 5.0;
@@ -71,6 +72,7 @@ struct KParams {
     double right_scale, wrong_scale;
     int8_t* grid;
     uint32_t* occ;
+    uint16_t* hist;
     AgentRec* agent;
     const int32_t* env_task;
     const int8_t* task_target;
@@ -155,6 +157,7 @@ struct Env {  // uniform across the lanes of a group
     int step_no, size, prev_size, max_int;
     uint64_t inv;  // 6 x int8
     int tis, active, target_size;
+    int dirty;  // the histogram changed since max_int was last refreshed (a change with wrong_placement == 0)
 };
 
 __device__ inline int inv_get(uint64_t inv, int i) { return (int)(int8_t)(inv >> (8 * i)); }
@@ -168,7 +171,8 @@ __device__ inline void env_load(Env& e, const AgentRec* rec) {
     // every lane reads the same 64 B line (one request per wave)
     const AgentRec r = *rec;
     e.x = r.x; e.y = r.y; e.z = r.z; e.yaw = r.yaw; e.pitch = r.pitch; e.vy = r.vy;
-    e.step_no = r.step_no; e.size = r.size; e.prev_size = r.prev_size; e.max_int = r.max_int;
+    e.step_no = r.step_no; e.size = r.size; e.prev_size = r.prev_size & 0x7fff; e.max_int = r.max_int;
+    e.dirty = ((uint16_t)r.prev_size >> 15) & 1;
     e.inv = r.inv_pack & 0x0000ffffffffffffull;
     const int code = (int)((r.inv_pack >> 48) & 3);
     e.tis = code == 0 ? 2 : code == 1 ? 4 : code == 2 ? 8 : 12;
@@ -179,7 +183,7 @@ __device__ inline void env_store(const Env& e, AgentRec* rec) {
     AgentRec r;
     r.x = e.x; r.y = e.y; r.z = e.z; r.yaw = e.yaw; r.pitch = e.pitch; r.vy = e.vy;
     r.step_no = (uint16_t)e.step_no; r.size = (int16_t)e.size;
-    r.prev_size = (int16_t)e.prev_size; r.max_int = (int16_t)e.max_int;
+    r.prev_size = (int16_t)(uint16_t)((e.prev_size & 0x7fff) | (e.dirty << 15)); r.max_int = (int16_t)e.max_int;
     const uint64_t code = e.tis == 2 ? 0 : e.tis == 4 ? 1 : e.tis == 8 ? 2 : 3;
     r.inv_pack = e.inv | (code << 48) | ((uint64_t)(e.active & 7) << 50) | ((uint64_t)(e.target_size & 0x7ff) << 53);
     *rec = r;

@@ -46,6 +46,7 @@ __device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_si
     e.step_no = 0;               // env.py:217
     e.prev_size = 0;             // _synthetic_task.reset(): prev_grid_size = 0, max_int = 0 (task.py:74-86)
     e.max_int = 0;
+    e.dirty = 0;
     e.target_size = meta->target_size;
     e.x = meta->pose[0]; e.y = meta->pose[1]; e.z = meta->pose[2];  // env.py:239-240
     e.yaw = meta->pose[3]; e.pitch = meta->pose[4];
@@ -68,6 +69,8 @@ __device__ inline void reset_rows_wave(const KParams& p, int env, int task, bool
         p.occ[(size_t)env * OCC_WORDS + lane] = v;
         if (occ_s) occ_s[lane] = v;
     }
+    // grid == start  =>  synthetic grid empty  =>  no votes
+    reinterpret_cast<uint4*>(p.hist + (size_t)env * HIST_ROW)[lane] = make_uint4(0, 0, 0, 0);
 }
 
 // obs of reset(): agentPos zeros, compass 0 (env.py:247-254)
@@ -273,15 +276,25 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int,
     return o;
 }
 
+// one pending histogram update: cell `cell` of env `env` changed its synthetic value a -> b
+struct ChangeReq {
+    int env, task, cell, a, b, max_old;
+    int bbox[4];
+};
+constexpr int REQ_CHUNK = 16;
+struct WaveScratch {
+    ChangeReq req[REQ_CHUNK];
+    int incmax[REQ_CHUNK];
+    int decflag[REQ_CHUNK];
+};
+
 template <int GS>
 struct BlockShared {
     static constexpr int EPB = BLOCK / GS;  // envs per block
     static constexpr int EPW = WAVE / GS;   // envs per wave
     double lut[IGW_LUT_N * 2];
-    uint32_t occ[EPB * OCC_PITCH];                       // occupancy bitmaps, one per env
-    alignas(16) int8_t rowG[WAVES_PER_BLOCK][STRIDE];    // per wave: int8 grid row (reward recompute only)
-    alignas(16) int8_t rowT[WAVES_PER_BLOCK][STRIDE];    // per wave: synthetic target row
-    uint32_t hist[WAVES_PER_BLOCK][HIST_PAD];
+    uint32_t occ[EPB * OCC_PITCH];  // occupancy bitmaps, one per env
+    WaveScratch ws[WAVES_PER_BLOCK];
 };
 
 __constant__ double IGW_TRIG_LUT_DEV[IGW_LUT_N * 2];
@@ -306,41 +319,102 @@ __device__ inline void load_occ_wave(const KParams& p, int first_env, uint32_t* 
     }
 }
 
-// max_intersection for every env of this wave that asked for it, one env at a time with all 64 lanes.
-// COHERENT: the launch itself may have written bytes of the grid row earlier (fused rollout).
-template <int GS, bool COHERENT>
-__device__ inline int resolve_max_intersection(const Grp<GS>& G, const KParams& p, BlockShared<GS>& sh, bool need,
-                                               int env, int task, bool has_start, int ch_idx, int ch_val,
-                                               int mi_cached) {
-    const int wave = threadIdx.x / WAVE;
-    uint64_t needm = __ballot(need);
-    int mi = mi_cached;
-    while (needm) {
-        const int l = __builtin_ctzll(needm);
-        const int gsel = l / GS;
-        if constexpr (GS == 64) needm = 0;
-        else if constexpr (GS == 1) needm &= needm - 1;
-        else needm &= ~(((1ull << GS) - 1ull) << (gsel * GS));
-        const int t_env = __builtin_amdgcn_readlane(env, l);
-        const int t_task = __builtin_amdgcn_readlane(task, l);
-        const int t_hs = __builtin_amdgcn_readlane((int)has_start, l);
-        const int t_idx = __builtin_amdgcn_readlane(ch_idx, l);
-        const int t_val = __builtin_amdgcn_readlane(ch_val, l);
-        const int* bbp = reinterpret_cast<const int*>(p.task_meta[t_task].bbox);
-        int bbox4[4] = {bbp[0], bbp[1], bbp[2], bbp[3]};
+__device__ inline uint32_t ld_agent_u16(const uint16_t* ptr) {  // L2-served (a fused rollout re-reads its own stores)
+    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Incremental maximal_intersection (tasks/task.py:147-161 as a persistent vote histogram): a step changes
+// at most one cell, so only the target cells on that cell's y level can gain or lose a vote -- 121 bytes
+// of the synthetic target and a handful of 16-bit bins instead of target x grid.  All changed envs of the
+// wave are flattened into (env, target cell) work items so their memory latencies overlap.
+// Outputs per env: the largest value any incremented bin reached, and whether a bin that held
+// `max_old` was decremented (then the maximum has to be rescanned).
+template <int GS>
+__device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveScratch& ws, bool changed, int env,
+                                       int task, int cell, int a, int b, int max_old, int& incmax_out,
+                                       bool& dec_out) {
+    incmax_out = 0;
+    dec_out = false;
+    const int lane = __lane_id();
+    const bool leader = changed && G.gl == 0;
+    const uint64_t mask = __ballot(leader);
+    if (mask == 0) return;
+    const int E = __builtin_popcountll(mask);
+    const int my_k = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    int inc_l = 0, dec_l = 0;
+    for (int base = 0; base < E; base += REQ_CHUNK) {
+        const int cnt = min(REQ_CHUNK, E - base);
+        const bool mine = leader && my_k >= base && my_k < base + cnt;
         wave_sync();
-        if (COHERENT) row_to_lds_wave_coherent(sh.rowG[wave], p.grid + (size_t)t_env * STRIDE);
-        else row_to_lds_wave(sh.rowG[wave], p.grid + (size_t)t_env * STRIDE);
-        row_to_lds_wave(sh.rowT[wave], p.task_target + (size_t)t_task * STRIDE);
+        if (mine) {
+            ChangeReq& r = ws.req[my_k - base];
+            r.env = env; r.task = task; r.cell = cell; r.a = a; r.b = b; r.max_old = max_old;
+            const int* bbp = reinterpret_cast<const int*>(p.task_meta[task].bbox);
+            r.bbox[0] = bbp[0]; r.bbox[1] = bbp[1]; r.bbox[2] = bbp[2]; r.bbox[3] = bbp[3];
+            ws.incmax[my_k - base] = 0;
+            ws.decflag[my_k - base] = 0;
+        }
         wave_sync();
-        if (__lane_id() == 0) sh.rowG[wave][t_idx] = (int8_t)t_val;  // this step's change is not in HBM yet
+        for (int item = lane; item < cnt * 128; item += WAVE) {
+            const int k = item >> 7, j = item & 127;
+            if (j >= LEVEL) continue;
+            const ChangeReq& r = ws.req[k];
+            const int y = r.cell / LEVEL, rem = r.cell % LEVEL;
+            const int tval = p.task_target[(size_t)r.task * STRIDE + y * LEVEL + j];
+            const bool dec = tval != 0 && tval == r.a;
+            const bool inc = tval != 0 && tval == r.b;
+            if (!(dec || inc)) continue;
+            const int gx = rem / 11, gz = rem % 11, tx = j / 11, tz = j % 11;
+            uint16_t* row = p.hist + (size_t)r.env * HIST_ROW;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
+                const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
+                const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
+                const int bb = r.bbox[q];
+                const int xmin = (int8_t)(bb & 0xff), xmax = (int8_t)((bb >> 8) & 0xff);
+                const int zmin = (int8_t)((bb >> 16) & 0xff), zmax = (int8_t)((bb >> 24) & 0xff);
+                const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
+                if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (tasks/task.py:62-72)
+                    const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
+                    const int old = (int)ld_agent_u16(row + bin);
+                    const int nw = old + (inc ? 1 : -1);
+                    row[bin] = (uint16_t)nw;
+                    if (inc) atomicMax(&ws.incmax[k], nw);
+                    else if (old == r.max_old) ws.decflag[k] = 1;
+                }
+            }
+        }
         wave_sync();
-        const MiResult r = max_intersection_wave<false>(
-            sh.rowG[wave], t_hs ? p.task_start + (size_t)t_task * STRIDE : nullptr, sh.rowT[wave],
-            sh.hist[wave], bbox4, 4);
-        if (G.g == gsel) mi = r.max_int;
+        if (mine) {
+            inc_l = ws.incmax[my_k - base];
+            dec_l = ws.decflag[my_k - base];
+        }
     }
-    return mi;
+    // the bins are re-read later (rescan below, next step of a fused rollout): let the stores land in L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    incmax_out = G.bcast(inc_l, 0);
+    dec_out = G.bcast(dec_l, 0) != 0;
+}
+
+// full maximum over the env's histogram, one env at a time with all 64 lanes (rare)
+template <int GS>
+__device__ inline int resolve_rescans(const Grp<GS>& G, const KParams& p, bool want, int env, int cur) {
+    uint64_t m = __ballot(want && G.gl == 0);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const int t_env = __builtin_amdgcn_readlane(env, l);
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(p.hist + (size_t)t_env * HIST_ROW);
+        int best = 0;
+        for (int w = __lane_id(); w < HIST_WORDS; w += WAVE) {
+            const uint32_t v = __hip_atomic_load(row + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            best = max(best, (int)max(v & 0xffff, v >> 16));
+        }
+        best = wave_max_i32(best);
+        if (__lane_id() / GS == l / GS) cur = best;
+    }
+    return cur;
 }
 
 // auto-reset rows of every done env of this wave (whole wave per env, coalesced)
@@ -380,7 +454,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     Env e = {};
     CellChange ch;
     ch.idx = -1; ch.old_val = ch.new_val = 0;
-    int size_new = 0, task = 0, env_max_int = 0;
+    int size_new = 0, task = 0, env_max_int = 0, syn_a = 0, syn_b = 0;
     bool need = false, has_start = false;
     const TaskMeta* meta = nullptr;
     int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
@@ -399,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
                                           placement == 1);
         }
         size_new = e.prev_size;
-        // the task row is only touched when the grid changed, an episode starts / ends, or SizeReward needs it
+        // the task table is only touched when the grid changed, an episode ends, or SizeReward needs it
         if (ch.idx >= 0 || (p.size_reward && e.step_no == 1)) {
             task = p.env_task[env];
             meta = p.task_meta + task;
@@ -408,14 +482,29 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
             if (ch.idx >= 0) {
                 int start_val = 0;
                 if (has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
+                syn_a = ch.old_val - start_val;  // synthetic grid = grid - start (env.py:290)
+                syn_b = ch.new_val - start_val;
                 size_new = e.prev_size + syn_size_delta(ch, start_val);
                 need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
-                if (p.debug & 1) need = false;
             }
         }
     }
-    const int mi = resolve_max_intersection<GS, false>(G, p, sh, need, env, task, has_start, ch.idx, ch.new_val,
-                                                       e.max_int);
+    int incmax = 0;
+    bool decd = false;
+    const bool changed = active && ch.idx >= 0 && !(p.debug & 1);
+    resolve_changes<GS>(G, p, sh.ws[wave], changed, env, task, ch.idx, syn_a, syn_b, e.max_int, incmax, decd);
+    int mi = e.max_int;
+    bool rescan = false;
+    if (changed) {
+        if (need) {  // max_int = maximal_intersection(grid)
+            rescan = decd || e.dirty;
+            mi = max(mi, incmax);
+            e.dirty = 0;
+        } else {
+            e.dirty = 1;  // the reference keeps its cached max_int here although the grid changed
+        }
+    }
+    mi = resolve_rescans<GS>(G, p, rescan, env, mi);
     StepOut o;
     o.reward = 0.0; o.done = false;
     bool do_reset = false;
@@ -442,6 +531,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
         else write_step_obs(p, env, e);
         env_store(e, p.agent + env);
         if (need) stat_add(p.stats, IGW_STAT_CHANGED, 1);
+        if (rescan) stat_add(p.stats, IGW_STAT_RESCANS, 1);
         if (do_reset) stat_add(p.stats, IGW_STAT_RESETS, 1);
     }
 }
@@ -477,14 +567,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
         env_max_int = meta->env_max_int;
     }
     wave_sync();
-    unsigned long long n_changed = 0, n_resets = 0;
+    unsigned long long n_changed = 0, n_resets = 0, n_rescans = 0;
     StepOut o;
     o.reward = 0.0; o.done = false;
     bool last_reset = false;
     for (long long t = 0; t < T; t++) {
         CellChange ch;
         ch.idx = -1; ch.old_val = ch.new_val = 0;
-        int size_new = 0;
+        int size_new = 0, syn_a = 0, syn_b = 0;
         bool need = false;
         if (active) {
             e.step_no = min(e.step_no + 1, 65535);
@@ -492,22 +582,40 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
             ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, action);
             int start_val = 0;
             if (ch.idx >= 0 && has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
+            syn_a = ch.old_val - start_val;
+            syn_b = ch.new_val - start_val;
             size_new = e.prev_size + syn_size_delta(ch, start_val);
             need = size_new != e.prev_size;
         }
-        const int mi = resolve_max_intersection<GS, true>(G, p, sh, need, env, task, has_start, ch.idx, ch.new_val,
-                                                          e.max_int);
+        int incmax = 0;
+        bool decd = false;
+        const bool changed = active && ch.idx >= 0;
+        resolve_changes<GS>(G, p, sh.ws[wave], changed, env, task, ch.idx, syn_a, syn_b, e.max_int, incmax, decd);
+        int mi = e.max_int;
+        bool rescan = false;
+        if (changed) {
+            if (need) {
+                rescan = decd || e.dirty;
+                mi = max(mi, incmax);
+                e.dirty = 0;
+            } else {
+                e.dirty = 1;
+            }
+        }
+        mi = resolve_rescans<GS>(G, p, rescan, env, mi);
         bool do_reset = false;
         if (active) {
             o = finish_step(p, e, env_max_int, size_new, mi);
             n_changed += need;
+            n_rescans += rescan;
             do_reset = o.done;
             last_reset = do_reset;
-            // colours go to HBM right away (a later break / reward recompute of this launch reads them)
+            // colours go to HBM right away (a later break of this launch reads them)
             if (ch.idx >= 0 && !do_reset && G.gl == 0) grid_g[ch.idx] = (int8_t)ch.new_val;
         }
         wave_sync();
         resolve_resets<GS>(G, p, do_reset, env, task, has_start, occ_wave_s);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (active && do_reset) {
             reset_env_regs(e, meta, false);
@@ -525,6 +633,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
         env_store(e, p.agent + env);
         if (n_changed) stat_add(p.stats, IGW_STAT_CHANGED, n_changed);
         if (n_resets) stat_add(p.stats, IGW_STAT_RESETS, n_resets);
+        if (n_rescans) stat_add(p.stats, IGW_STAT_RESCANS, n_rescans);
         stat_add(p.stats, IGW_STAT_STEPS, (unsigned long long)T);
     }
 }
@@ -837,15 +946,16 @@ int igw_destroy(igw_ctx* ctx) {
 
 int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
     if (!ctx || !b) return fail(IGW_ERR_INVALID, "igw_bind_buffers: null argument");
-    if (!b->grid || !b->occ || !b->agent || !b->env_task || !b->task_target || !b->task_start ||
+    if (!b->grid || !b->occ || !b->hist || !b->agent || !b->env_task || !b->task_target || !b->task_start ||
         !b->task_start_occ || !b->task_meta || !b->agent_pos || !b->inventory || !b->compass || !b->reward || !b->done)
         return fail(IGW_ERR_INVALID, "igw_bind_buffers: a required buffer is null");
-    if (((uintptr_t)b->grid | (uintptr_t)b->occ | (uintptr_t)b->agent | (uintptr_t)b->task_target |
+    if (((uintptr_t)b->grid | (uintptr_t)b->occ | (uintptr_t)b->hist | (uintptr_t)b->agent | (uintptr_t)b->task_target |
          (uintptr_t)b->task_start | (uintptr_t)b->task_start_occ | (uintptr_t)b->task_meta) & 15)
         return fail(IGW_ERR_INVALID, "igw_bind_buffers: grid / occ / agent / task buffers must be 16-byte aligned");
     KParams& k = ctx->kp;
     k.grid = b->grid;
     k.occ = b->occ;
+    k.hist = b->hist;
     k.task_start_occ = b->task_start_occ;
     k.agent = reinterpret_cast<AgentRec*>(b->agent);
     k.env_task = b->env_task;

@@ -53,6 +53,7 @@ class VecGridWorld:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         self.grid_buf = z((N, L.GRID_STRIDE), torch.int8)
         self.occ_buf = z((N, L.OCC_WORDS), torch.int32)
+        self.hist_buf = z((N, L.HIST_ROW), torch.int16)
         self.agent_buf = z((N, L.AGENT_BYTES), torch.uint8)
         self.env_task = z((N,), torch.int32)
         self.task_target = z((T, L.GRID_STRIDE), torch.int8)
@@ -74,7 +75,7 @@ class VecGridWorld:
                             int(debug_flags))
         self.ctx = C.c_void_p()
         L.check(self.lib.igw_create(C.byref(self.cfg), C.byref(self.ctx)), 'igw_create')
-        b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.occ_buf, self.agent_buf, self.env_task,
+        b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.occ_buf, self.hist_buf, self.agent_buf, self.env_task,
                                                 self.task_target, self.task_start, self.task_start_occ, self.task_meta,
                                                 self.agent_pos, self.inventory, self.compass, self.reward, self.done,
                                                 self.stats_buf)])
@@ -183,7 +184,7 @@ class VecGridWorld:
     def stats(self):
         s = self.stats_buf.sum(0).cpu()
         return {'changed': int(s[L.STAT_CHANGED]), 'resets': int(s[L.STAT_RESETS]),
-                'rollout_steps': int(s[L.STAT_STEPS])}
+                'rollout_steps': int(s[L.STAT_STEPS]), 'rescans': int(s[L.STAT_RESCANS])}
 
     def internals(self):
         """float64 [N,8]: x, y, z, yaw, pitch, dy, time_int_steps, active_block (debug / parity)."""
@@ -199,7 +200,8 @@ class VecGridWorld:
         raw = self.agent_buf.cpu().numpy()
         return {'step_no': raw[:, 48:50].copy().view(np.uint16)[:, 0].astype(np.int64),
                 'size': raw[:, 50:52].copy().view(np.int16)[:, 0].astype(np.int64),
-                'prev_size': raw[:, 52:54].copy().view(np.int16)[:, 0].astype(np.int64),
+                'prev_size': (raw[:, 52:54].copy().view(np.uint16)[:, 0] & 0x7fff).astype(np.int64),
+                'dirty': (raw[:, 52:54].copy().view(np.uint16)[:, 0] >> 15).astype(np.int64),
                 'max_int': raw[:, 54:56].copy().view(np.int16)[:, 0].astype(np.int64)}
 
 

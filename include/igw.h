@@ -46,6 +46,9 @@ extern "C" {
 /* occupancy bitmap of the 1089 cells (bit = cell index), 36 dwords = 144 B per env: the per-step
  * working set of the physics; kept in sync with `grid` by every kernel */
 #define IGW_OCC_WORDS 36
+/* persistent per-env vote histogram of maximal_intersection: for each of the 4 rotations the 11 x 11
+ * admissible translations (bounding-box relative), uint16 counts, row padded to 512 entries */
+#define IGW_HIST_ROW 512
 /* bytes of per-env agent state and of per-task metadata (layouts below) */
 #define IGW_AGENT_BYTES 64
 #define IGW_TASK_META_BYTES 128
@@ -54,6 +57,7 @@ extern "C" {
 #define IGW_STAT_CHANGED 0 /* env-steps whose block count changed (max_intersection recomputed) */
 #define IGW_STAT_RESETS 1  /* auto-resets performed */
 #define IGW_STAT_STEPS 2   /* env-steps executed by igw_rollout_walking */
+#define IGW_STAT_RESCANS 3 /* full histogram rescans (a bin holding the maximum was decremented) */
 
 enum igw_status {
     IGW_OK = 0,
@@ -93,7 +97,8 @@ typedef struct igw_config {
  *   40 f64 vy             agent.dy            (leaks through reset)
  *   48 u16 step_no        GridWorld.step_no   (saturates at 65535)
  *   50 i16 size           SizeReward.size
- *   52 i16 prev_size      _synthetic_task.prev_grid_size
+ *   52 u16 prev_size      _synthetic_task.prev_grid_size (bits 0-14); bit 15: histogram changed while the
+ *                         reference kept its cached max_int (a change with wrong_placement == 0)
  *   54 i16 max_int        _synthetic_task.max_int
  *   56 i8  inventory[6]   agent.inventory
  *   62 u16 pack           bits 0-1 agent.time_int_steps code (0,1,2,3 = 2,4,8,12), bits 2-4
@@ -115,6 +120,7 @@ typedef struct igw_buffers {
     /* state */
     int8_t* grid;          /* [N][IGW_GRID_STRIDE]   world grid (colours) == obs 'grid' */
     uint32_t* occ;         /* [N][IGW_OCC_WORDS]     occupancy bitmap of grid */
+    uint16_t* hist;        /* [N][IGW_HIST_ROW]      vote histogram of (grid - start) against the synthetic target */
     void* agent;           /* [N][IGW_AGENT_BYTES] */
     int32_t* env_task;     /* [N] index into the task table */
     /* task table */

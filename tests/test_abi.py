@@ -35,7 +35,7 @@ def test_layout_constants_match_header():
         m = re.search(r'#define\s+%s\s+(\d+)' % name, src)
         assert m and int(m.group(1)) == val, name
     assert ctypes.sizeof(_lib.Config) == 56
-    assert ctypes.sizeof(_lib.Buffers) == 14 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.Buffers) == 15 * ctypes.sizeof(ctypes.c_void_p)
 
 
 def test_fails_loudly_without_device():

@@ -134,6 +134,44 @@ def test_rt20_autoreset_vs_oracle(gs):
     st = env.stats()
     assert st['resets'] >= n and 0.01 < st['changed'] / (n * T) < 0.3
     _check_occ(env)
+    _check_hist(env, tg, sample=range(0, n, 7))
+
+
+def _expected_hist(target_syn, grid_syn):
+    """The vote histogram the kernels keep per env, from first principles: for every rotation
+    (tasks/task.py:47-56) and every admissible translation (bounding-box rule == tasks/task.py:62-72)
+    the intersection count of tasks/task.py:138-145, laid out [rot][dx - dxlo][dz - dzlo] with pitch 11."""
+    out = np.zeros(512, np.uint16)
+    t = target_syn.astype(np.int32)
+    g = grid_syn.astype(np.int32)
+    if not t.any():
+        return out
+    for r in range(4):
+        tr = np.rot90(t, k=-r, axes=(1, 2))
+        _, xs, zs = np.nonzero(tr)
+        dxlo, dxhi, dzlo, dzhi = xs.max() - 10, xs.min(), zs.max() - 10, zs.min()
+        for dx in range(dxlo, dxhi + 1):
+            for dz in range(dzlo, dzhi + 1):
+                st = tr[:, max(dx, 0):11 + min(dx, 0), max(dz, 0):11 + min(dz, 0)]
+                sg = g[:, max(-dx, 0):11 + min(-dx, 0), max(-dz, 0):11 + min(-dz, 0)]
+                out[r * 121 + (dx - dxlo) * 11 + (dz - dzlo)] = ((st == sg) & (st != 0)).sum()
+    return out
+
+
+def _check_hist(env, targets, starts=None, sample=None):
+    """Persistent histogram == histogram recomputed from scratch; max_int == its maximum unless the
+    reference itself holds a stale cached value (dirty bit)."""
+    torch.cuda.synchronize()
+    grid = env.grid.cpu().numpy().astype(np.int32)
+    hist = env.hist_buf.cpu().numpy().view(np.uint16)
+    ts = env.task_state()
+    idx = range(env.num_envs) if sample is None else sample
+    for e in idx:
+        st = np.zeros((9, 11, 11), np.int32) if starts is None else starts[e].astype(np.int32)
+        want = _expected_hist(targets[e].astype(np.int32) - st, grid[e] - st)
+        assert np.array_equal(hist[e], want), f'env {e}: histogram differs from a fresh recount'
+        if not ts['dirty'][e]:
+            assert ts['max_int'][e] == want.max(), f'env {e}: max_int {ts["max_int"][e]} vs {want.max()}'
 
 
 def _check_occ(env):
@@ -177,6 +215,42 @@ def test_fused_rollout_vs_oracle(gs):
     torch.cuda.synchronize()
     assert torch.equal(env.grid_buf, env2.grid_buf) and torch.equal(env.agent_buf, env2.agent_buf)
     assert torch.equal(env.occ_buf, env2.occ_buf)
+    _check_occ(env)
+
+
+@pytest.mark.parametrize('gs', [0, 4, 1])
+def test_start_grids_incremental_reward_vs_oracle(gs):
+    """CDM structures with partial starting grids (negative synthetic ids, blocks to remove): exercises
+    histogram decrements, rescans and the reference's stale-cache case (a change that leaves the block
+    count unchanged).  Checked against the oracle every few steps and against a fresh recount."""
+    from gridworld_amd import VecGridWorld
+    from oracle import oracle as O
+    fx = GR.load_fixture('s2_walk_cdm')
+    reps = 24
+    tg = np.tile(fx['targets'], (reps, 1, 1, 1))
+    st = np.tile(fx['starts'], (reps, 1, 1, 1))
+    n, T = len(tg), 400
+    kw = dict(size_reward=False, max_steps=1000)
+    env = VecGridWorld(n, autoreset=False, lanes_per_env=gs, **kw)
+    env.set_tasks(tg, st)
+    env.reset()
+    ob = O.OracleBatch(n, **kw)
+    ob.set_tasks(tg, st)
+    ob.reset()
+    rng = np.random.RandomState(77)
+    # a policy that looks down and places / breaks a lot, so start blocks get broken and replaced
+    acts = rng.choice([1, 2, 3, 4, 5, 7, 9, 12, 13, 14, 15, 16, 16, 16, 17, 17], size=(T, n)).astype(np.int32)
+    acts[:6] = 14
+    for t in range(T):
+        env.step(torch.as_tensor(acts[t]))
+        ob.step_walking(acts[t], nthreads=8)
+        if t % 20 == 19 or t == T - 1:
+            _compare(env, ob, f'step {t}')
+    stt = env.stats()
+    ts = env.task_state()
+    print('changed', stt['changed'], 'rescans', stt['rescans'], 'dirty now', int(ts['dirty'].sum()))
+    assert stt['rescans'] > 0
+    _check_hist(env, tg, st, sample=range(0, n, 5))
     _check_occ(env)
 
 
