@@ -51,7 +51,7 @@ def cpu_baseline(seed):
     t = time.perf_counter()
     b.rollout_walking(25, seed, autoreset=True, nthreads=cores)
     rate0 = n0 * 25 / (time.perf_counter() - t)
-    n = int(min(8192, max(n0, (rate0 * 10 / T) // 64 * 64)))
+    n = int(min(65536, max(n0, (rate0 * 12 / T) // 64 * 64)))  # ~12 s of all-core work
     tg = workloads.rt20(n, seed).numpy()
     b = O.OracleBatch(n, **kw)
     b.set_tasks(tg)
@@ -77,7 +77,7 @@ def load_traffic():
     """HBM bytes per launch from the committed PMC profile (profiles/*traffic*.json), or None."""
     import glob
     best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic*.json'))):
+    for p in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic.json'))):
         try:
             with open(p) as f:
                 best = json.load(f)
@@ -155,6 +155,7 @@ def main():
 
     if rank != 0:
         return
+    lanes = env.cfg.lanes_per_env or 4
     p = (st1['changed'] - st0['changed']) / float(N * K)
     resets = st1['resets'] - st0['resets']
     bytes_per_step = BYTES_BASE + BYTES_CHANGED * p
@@ -176,13 +177,13 @@ def main():
         'config': {'workload': 'configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block '
                                'targets (rt20), full maximal_intersection reward, uniform random actions, '
                                'auto-reset at done (max_steps=250)',
-                   'envs_per_gpu': N, 'total_envs': N * world, 'lanes_per_env': env.cfg.lanes_per_env or 64,
+                   'envs_per_gpu': N, 'total_envs': N * world, 'lanes_per_env': lanes,
                    'launches_per_step': 1, 'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None if traffic is None else traffic.get('hbm_bytes_per_launch'),
-                     'kernel': 'igw::step_kernel<64, walking>', 'kernel_avg_ms': kernel_ms,
+                     'kernel': 'igw::step_kernel<%d, 0>' % lanes, 'kernel_avg_ms': kernel_ms,
                      'algorithmic_bytes_per_env_step': bytes_per_step,
                      'algorithmic_bytes_per_launch': N * bytes_per_step},
     }

@@ -908,7 +908,7 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     if (cfg->max_steps < 1 || cfg->max_steps > 65534) return fail(IGW_ERR_INVALID, "igw_create: max_steps must be in 1..65534");
     if (cfg->action_space != IGW_WALKING_DISCRETE && cfg->action_space != IGW_FLYING)
         return fail(IGW_ERR_INVALID, "igw_create: unknown action_space");
-    int gs = cfg->lanes_per_env ? cfg->lanes_per_env : 64;
+    int gs = cfg->lanes_per_env ? cfg->lanes_per_env : IGW_DEFAULT_LANES_PER_ENV;
     if (gs != 64 && gs != 32 && gs != 16 && gs != 8 && gs != 4 && gs != 2 && gs != 1)
         return fail(IGW_ERR_INVALID, "igw_create: lanes_per_env must be 0 or a power of two in 1..64");
     int n = 0;

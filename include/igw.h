@@ -34,6 +34,9 @@ extern "C" {
 #endif
 
 #define IGW_VERSION 1
+/* lanes of a wavefront that cooperate on one env when igw_config.lanes_per_env == 0 (measured optimum
+ * for per-step launches at 65,536 envs on MI355X; 64 = one wavefront per env) */
+#define IGW_DEFAULT_LANES_PER_ENV 4
 
 /* dense voxel grid [y+1][x+5][z+5], int8 (env.py:34, 136-142) */
 #define IGW_GRID_Y 9

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-for g in 64 16; do
+for g in 4 1; do
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
   d=gpurun_out/pmc_${g}_$(echo $set | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -- python3 bench.py --lanes-per-env $g --no-cpu-baseline --no-fused --steps 60 --warmup 10 > /dev/null 2> $d.log
