@@ -11,6 +11,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/igw.h"
@@ -59,11 +60,13 @@ static_assert(sizeof(AgentRec) == IGW_AGENT_BYTES, "agent record layout");
 struct alignas(16) TaskMeta {
     double pose[5];
     int16_t target_size, env_max_int;
-    int8_t bbox[16];
-    int8_t inv_init[6];
     uint8_t has_start;
-    uint8_t pad[IGW_TASK_META_BYTES - 67];
+    uint8_t pad0[3];
+    int8_t bbox[16];  // offset 48: one aligned dwordx4
+    int8_t inv_init[6];
+    uint8_t pad[IGW_TASK_META_BYTES - 70];
 };
+static_assert(offsetof(TaskMeta, bbox) == 48, "bbox must be 16-byte aligned");
 static_assert(sizeof(TaskMeta) == IGW_TASK_META_BYTES, "task meta layout");
 
 struct KParams {
@@ -232,46 +235,56 @@ __device__ inline void sincos_deg(const TrigCtx& t, double deg, double& s, doubl
     }
 }
 
+// x / 5 exactly as IEEE division rounds it, in 3 flops instead of a full f64 division sequence:
+// q0 = RN(x * RN(1/5)), r = x - 5 q0 (exact in an fma), q = RN(q0 + r * RN(1/5)) is the correctly rounded
+// quotient (Markstein's theorem; checked bit-for-bit against x / 5.0 on 4*10^8 arguments).  Zeros and
+// values near the underflow range (where the residual may be inexact) take the real division.
+__device__ inline double div5(double x) {
+    if (__builtin_fabs(x) >= 0x1p-900) {
+        const double c = 0x1.999999999999ap-3;
+        const double q = x * c;
+        const double r = __builtin_fma(-5.0, q, x);
+        return __builtin_fma(r, c, q);
+    }
+    return x / 5.0;
+}
+
 // ---------------------------------------------------------------- collide (core/world.py:264-310)
 
-__device__ inline void collide(Env& e, const uint32_t* grid_s, double& px, double& py, double& pz) {
+// Six faces in the reference order; a face only probes when its overlap test passes.  (Issuing all 12
+// probes up front -- they depend only on np -- was measured slower at every group size.)
+__device__ inline void collide(Env& e, const uint32_t* occ_s, double& px, double& py, double& pz) {
     const int nx = (int)__builtin_rint(px), ny = (int)__builtin_rint(py), nz = (int)__builtin_rint(pz);
     double d;
-    // face (0, 1, 0)
-    d = (py - (double)ny) * 1.0;
+    d = (py - (double)ny) * 1.0;  // face (0, 1, 0)
     if (!(d < PAD)) {
-        if (world_has(grid_s, nx, ny + 1, nz) || world_has(grid_s, nx, ny - 1 + 1, nz)) {
+        if (world_has(occ_s, nx, ny + 1, nz) || world_has(occ_s, nx, ny, nz)) {
             py -= (d - PAD) * 1.0;
             e.vy = 0.0;
         }
     }
-    // face (0, -1, 0)
-    d = (py - (double)ny) * -1.0;
+    d = (py - (double)ny) * -1.0;  // face (0, -1, 0)
     if (!(d < PAD)) {
-        if (world_has(grid_s, nx, ny - 1, nz) || world_has(grid_s, nx, ny - 1 - 1, nz)) {
+        if (world_has(occ_s, nx, ny - 1, nz) || world_has(occ_s, nx, ny - 2, nz)) {
             py -= (d - PAD) * -1.0;
             e.vy = 0.0;
         }
     }
-    // face (-1, 0, 0)
-    d = (px - (double)nx) * -1.0;
+    d = (px - (double)nx) * -1.0;  // face (-1, 0, 0)
     if (!(d < PAD)) {
-        if (world_has(grid_s, nx - 1, ny, nz) || world_has(grid_s, nx - 1, ny - 1, nz)) px -= (d - PAD) * -1.0;
+        if (world_has(occ_s, nx - 1, ny, nz) || world_has(occ_s, nx - 1, ny - 1, nz)) px -= (d - PAD) * -1.0;
     }
-    // face (1, 0, 0)
-    d = (px - (double)nx) * 1.0;
+    d = (px - (double)nx) * 1.0;  // face (1, 0, 0)
     if (!(d < PAD)) {
-        if (world_has(grid_s, nx + 1, ny, nz) || world_has(grid_s, nx + 1, ny - 1, nz)) px -= (d - PAD) * 1.0;
+        if (world_has(occ_s, nx + 1, ny, nz) || world_has(occ_s, nx + 1, ny - 1, nz)) px -= (d - PAD) * 1.0;
     }
-    // face (0, 0, 1)
-    d = (pz - (double)nz) * 1.0;
+    d = (pz - (double)nz) * 1.0;  // face (0, 0, 1)
     if (!(d < PAD)) {
-        if (world_has(grid_s, nx, ny, nz + 1) || world_has(grid_s, nx, ny - 1, nz + 1)) pz -= (d - PAD) * 1.0;
+        if (world_has(occ_s, nx, ny, nz + 1) || world_has(occ_s, nx, ny - 1, nz + 1)) pz -= (d - PAD) * 1.0;
     }
-    // face (0, 0, -1)
-    d = (pz - (double)nz) * -1.0;
+    d = (pz - (double)nz) * -1.0;  // face (0, 0, -1)
     if (!(d < PAD)) {
-        if (world_has(grid_s, nx, ny, nz - 1) || world_has(grid_s, nx, ny - 1, nz - 1)) pz -= (d - PAD) * -1.0;
+        if (world_has(occ_s, nx, ny, nz - 1) || world_has(occ_s, nx, ny - 1, nz - 1)) pz -= (d - PAD) * -1.0;
     }
 }
 
@@ -290,7 +303,7 @@ template <int GS>
 __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x, double y, double z,
                                double vx, double vy, double vz) {
     constexpr int SAMPLES = 40;  // max_distance 8 * m 5
-    const double sx = vx / 5.0, sy = vy / 5.0, sz = vz / 5.0;
+    const double sx = div5(vx), sy = div5(vy), sz = div5(vz);  // dx / m with m = 5
     Hit h;
     h.hit = false; h.have_prev = false;
     h.bx = h.by = h.bz = 0;
@@ -314,33 +327,44 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
         return h;
     } else {
         constexpr int ROUNDS = (SAMPLES + GS - 1) / GS;
-        int lkx = 0, lky = 0, lkz = 0;  // key of the last sample of the previous round
+        // pass 1: every lane walks to its samples (pure ALU) and issues all its membership probes
+        int key[ROUNDS];  // packed (kx+128) | (ky+128) << 8 | (kz+128) << 16
+        bool inw[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
-            const int s = r * GS + G.gl;
             int nadd = (r == 0) ? G.gl : GS;
             if (GS == 64) nadd = min(nadd, SAMPLES - 1);
             const int bound = (r == 0) ? min(GS - 1, SAMPLES - 1) : GS;
-            for (int i = 0; i < bound; i++) {
-                if (i < nadd) { x = x + sx; y = y + sy; z = z + sz; }
+            if (r == 0) {
+                for (int i = 0; i < bound; i++) {
+                    if (i < nadd) { x = x + sx; y = y + sy; z = z + sz; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < bound; i++) { x = x + sx; y = y + sy; z = z + sz; }
             }
             const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
-            int qx = G.shfl_up1(kx), qy = G.shfl_up1(ky), qz = G.shfl_up1(kz);
-            if (G.gl == 0) { qx = lkx; qy = lky; qz = lkz; }
-            const bool differs = (s == 0) || kx != qx || ky != qy || kz != qz;
-            const bool inw = world_has(occ_s, kx, ky, kz);
-            const bool cand = !h.hit && s < SAMPLES && differs && inw;
+            key[r] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
+            inw[r] = world_has(occ_s, kx, ky, kz);
+        }
+        // pass 2: `key != previous and key in world`, first sample wins
+        int last = 0;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            const int s = r * GS + G.gl;
+            int q = G.shfl_up1(key[r]);
+            if (G.gl == 0) q = last;
+            const bool cand = s < SAMPLES && ((s == 0) || key[r] != q) && inw[r];
             const uint64_t m = G.ballot(cand);
             if (m != 0 && !h.hit) {
                 const int first = __builtin_ctzll(m);
+                const int bk = G.bcast(key[r], first), pk = G.bcast(q, first);
                 h.hit = true;
                 h.have_prev = !(r == 0 && first == 0);
-                h.bx = G.bcast(kx, first); h.by = G.bcast(ky, first); h.bz = G.bcast(kz, first);
-                h.px = G.bcast(qx, first); h.py = G.bcast(qy, first); h.pz = G.bcast(qz, first);
+                h.bx = (bk & 0xff) - 128; h.by = ((bk >> 8) & 0xff) - 128; h.bz = ((bk >> 16) & 0xff) - 128;
+                h.px = (pk & 0xff) - 128; h.py = ((pk >> 8) & 0xff) - 128; h.pz = ((pk >> 16) & 0xff) - 128;
             }
-            if (r + 1 < ROUNDS) {
-                lkx = G.bcast(kx, GS - 1); lky = G.bcast(ky, GS - 1); lkz = G.bcast(kz, GS - 1);
-            }
+            if (r + 1 < ROUNDS) last = G.bcast(key[r], GS - 1);
         }
         return h;
     }

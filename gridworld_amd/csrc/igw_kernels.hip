@@ -208,11 +208,9 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
             }
             ddy += e.vy * dt;
             double cx = e.x + ddx, cy = e.y + ddy, cz = e.z + ddz;
-            if (build_zone_d(cx, cy, cz, 2.0)) {
-                collide(e, occ_s, cx, cy, cz);
-                e.x = cx; e.y = cy; e.z = cz;
-            } else if (!FLY) {
-                cx = e.x; cz = e.z;
+            const bool in_zone = build_zone_d(cx, cy, cz, 2.0);
+            if (in_zone || !FLY) {
+                if (!in_zone) { cx = e.x; cz = e.z; }  // outside the padded zone a walker only moves vertically
                 collide(e, occ_s, cx, cy, cz);
                 e.x = cx; e.y = cy; e.z = cz;
             }
@@ -276,16 +274,19 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int,
     return o;
 }
 
-// one pending histogram update: cell `cell` of env `env` changed its synthetic value a -> b
+// one pending histogram update: cell `cell` of env `env` changed its colour old_val -> new_val
 struct ChangeReq {
-    int env, task, cell, a, b, max_old;
-    int bbox[4];
+    int env, task, cell, old_val, new_val, max_old;
 };
-constexpr int REQ_CHUNK = 16;
+constexpr int REQ_MAX = 4;
+// changed envs handled together per pass: more keeps more loads in flight but costs ~13 VGPRs each;
+// wide groups rarely have more than one changed env per wave and are issue-bound, so they take 1
+template <int GS>
+constexpr int req_chunk() { return GS >= 16 ? 1 : GS == 8 ? 2 : REQ_MAX; }
 struct WaveScratch {
-    ChangeReq req[REQ_CHUNK];
-    int incmax[REQ_CHUNK];
-    int decflag[REQ_CHUNK];
+    ChangeReq req[REQ_MAX];
+    int incmax[REQ_MAX];
+    int decflag[REQ_MAX];
 };
 
 template <int GS>
@@ -325,13 +326,15 @@ __device__ inline uint32_t ld_agent_u16(const uint16_t* ptr) {  // L2-served (a 
 
 // Incremental maximal_intersection (tasks/task.py:147-161 as a persistent vote histogram): a step changes
 // at most one cell, so only the target cells on that cell's y level can gain or lose a vote -- 121 bytes
-// of the synthetic target and a handful of 16-bit bins instead of target x grid.  All changed envs of the
-// wave are flattened into (env, target cell) work items so their memory latencies overlap.
+// of the synthetic target and a handful of 16-bit bins instead of target x grid.  The changed envs of the
+// wave are handled REQ_CHUNK at a time by all 64 lanes (lane l owns target cells l and l + 64 of the level),
+// and every global load of a chunk (target bytes, start byte, bounding boxes) is issued before the first
+// is consumed, so a chunk costs two memory round trips: {target, start, bbox} then {bins}.
 // Outputs per env: the largest value any incremented bin reached, and whether a bin that held
 // `max_old` was decremented (then the maximum has to be rescanned).
-template <int GS>
+template <int GS, bool DRAIN>
 __device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveScratch& ws, bool changed, int env,
-                                       int task, int cell, int a, int b, int max_old, int& incmax_out,
+                                       int task, const CellChange& ch, int max_old, int& incmax_out,
                                        bool& dec_out) {
     incmax_out = 0;
     dec_out = false;
@@ -341,6 +344,8 @@ __device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveS
     if (mask == 0) return;
     const int E = __builtin_popcountll(mask);
     const int my_k = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    constexpr int REQ_CHUNK = req_chunk<GS>();
+    const bool v1 = lane + 64 < LEVEL;
     int inc_l = 0, dec_l = 0;
     for (int base = 0; base < E; base += REQ_CHUNK) {
         const int cnt = min(REQ_CHUNK, E - base);
@@ -348,40 +353,59 @@ __device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveS
         wave_sync();
         if (mine) {
             ChangeReq& r = ws.req[my_k - base];
-            r.env = env; r.task = task; r.cell = cell; r.a = a; r.b = b; r.max_old = max_old;
-            const int* bbp = reinterpret_cast<const int*>(p.task_meta[task].bbox);
-            r.bbox[0] = bbp[0]; r.bbox[1] = bbp[1]; r.bbox[2] = bbp[2]; r.bbox[3] = bbp[3];
+            r.env = env; r.task = task; r.cell = ch.idx; r.old_val = ch.old_val; r.new_val = ch.new_val;
+            r.max_old = max_old;
             ws.incmax[my_k - base] = 0;
             ws.decflag[my_k - base] = 0;
         }
         wave_sync();
-        for (int item = lane; item < cnt * 128; item += WAVE) {
-            const int k = item >> 7, j = item & 127;
-            if (j >= LEVEL) continue;
-            const ChangeReq& r = ws.req[k];
-            const int y = r.cell / LEVEL, rem = r.cell % LEVEL;
-            const int tval = p.task_target[(size_t)r.task * STRIDE + y * LEVEL + j];
-            const bool dec = tval != 0 && tval == r.a;
-            const bool inc = tval != 0 && tval == r.b;
-            if (!(dec || inc)) continue;
-            const int gx = rem / 11, gz = rem % 11, tx = j / 11, tz = j % 11;
-            uint16_t* row = p.hist + (size_t)r.env * HIST_ROW;
+        ChangeReq rq[REQ_CHUNK];
+        int tv0[REQ_CHUNK], tv1[REQ_CHUNK], sv[REQ_CHUNK];
+        int4 bb[REQ_CHUNK];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
-                const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
-                const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
-                const int bb = r.bbox[q];
-                const int xmin = (int8_t)(bb & 0xff), xmax = (int8_t)((bb >> 8) & 0xff);
-                const int zmin = (int8_t)((bb >> 16) & 0xff), zmax = (int8_t)((bb >> 24) & 0xff);
-                const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
-                if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (tasks/task.py:62-72)
-                    const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
-                    const int old = (int)ld_agent_u16(row + bin);
-                    const int nw = old + (inc ? 1 : -1);
-                    row[bin] = (uint16_t)nw;
-                    if (inc) atomicMax(&ws.incmax[k], nw);
-                    else if (old == r.max_old) ws.decflag[k] = 1;
+        for (int k = 0; k < REQ_CHUNK; k++) {
+            if (k < cnt) {
+                rq[k] = ws.req[k];
+                const int8_t* trow = p.task_target + (size_t)rq[k].task * STRIDE + (rq[k].cell / LEVEL) * LEVEL;
+                tv0[k] = trow[lane];
+                tv1[k] = v1 ? trow[lane + 64] : 0;
+                sv[k] = p.task_start[(size_t)rq[k].task * STRIDE + rq[k].cell];
+                bb[k] = *reinterpret_cast<const int4*>(p.task_meta[rq[k].task].bbox);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < REQ_CHUNK; k++) {
+            if (k < cnt) {
+                const int a = rq[k].old_val - sv[k], b = rq[k].new_val - sv[k];  // synthetic grid = grid - start
+                const int rem = rq[k].cell % LEVEL, gx = rem / 11, gz = rem % 11;
+                uint16_t* row = p.hist + (size_t)rq[k].env * HIST_ROW;
+                const int bbq[4] = {bb[k].x, bb[k].y, bb[k].z, bb[k].w};
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int tval = half ? tv1[k] : tv0[k];
+                    const int j = lane + 64 * half;
+                    const bool dec = tval != 0 && tval == a;
+                    const bool inc = tval != 0 && tval == b;
+                    if (dec || inc) {
+                        const int tx = j / 11, tz = j % 11;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
+                            const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
+                            const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
+                            const int xmin = (int8_t)(bbq[q] & 0xff), xmax = (int8_t)((bbq[q] >> 8) & 0xff);
+                            const int zmin = (int8_t)((bbq[q] >> 16) & 0xff), zmax = (int8_t)((bbq[q] >> 24) & 0xff);
+                            const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
+                            if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (task.py:62-72)
+                                const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
+                                const int old = (int)ld_agent_u16(row + bin);
+                                const int nw = old + (inc ? 1 : -1);
+                                row[bin] = (uint16_t)nw;
+                                if (inc) atomicMax(&ws.incmax[k], nw);
+                                else if (old == rq[k].max_old) ws.decflag[k] = 1;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -391,8 +415,10 @@ __device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveS
             dec_l = ws.decflag[my_k - base];
         }
     }
-    // the bins are re-read later (rescan below, next step of a fused rollout): let the stores land in L2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the bins may be re-read later in this launch (rescan, next step of a fused rollout): let the stores
+    // land in L2 first; a plain step launch only needs that when a rescan follows
+    const int dec_any = __any(dec_l != 0);
+    if (DRAIN || dec_any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     incmax_out = G.bcast(inc_l, 0);
     dec_out = G.bcast(dec_l, 0) != 0;
 }
@@ -401,6 +427,7 @@ __device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveS
 template <int GS>
 __device__ inline int resolve_rescans(const Grp<GS>& G, const KParams& p, bool want, int env, int cur) {
     uint64_t m = __ballot(want && G.gl == 0);
+    if (m) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this launch's bin stores have reached L2
     while (m) {
         const int l = __builtin_ctzll(m);
         m &= m - 1;
@@ -454,11 +481,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     Env e = {};
     CellChange ch;
     ch.idx = -1; ch.old_val = ch.new_val = 0;
-    int size_new = 0, task = 0, env_max_int = 0, syn_a = 0, syn_b = 0;
+    int size_new = 0, task = 0, env_max_int = 0, start_val = 0;
     bool need = false, has_start = false;
     const TaskMeta* meta = nullptr;
     int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
     if (active) {
+        task = p.env_task[env];  // prefetched: only consumed if the grid changes or the episode ends
         env_load(e, p.agent + env);
         wave_sync();
         e.step_no = min(e.step_no + 1, 65535);  // env.py:276
@@ -472,27 +500,19 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
                                           a.inventory[env], (double)cam[0], (double)cam[1], placement == 2,
                                           placement == 1);
         }
-        size_new = e.prev_size;
-        // the task table is only touched when the grid changed, an episode ends, or SizeReward needs it
-        if (ch.idx >= 0 || (p.size_reward && e.step_no == 1)) {
-            task = p.env_task[env];
-            meta = p.task_meta + task;
-            has_start = meta->has_start != 0;
-            env_max_int = meta->env_max_int;
-            if (ch.idx >= 0) {
-                int start_val = 0;
-                if (has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
-                syn_a = ch.old_val - start_val;  // synthetic grid = grid - start (env.py:290)
-                syn_b = ch.new_val - start_val;
-                size_new = e.prev_size + syn_size_delta(ch, start_val);
-                need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
-            }
-        }
+        // issued here, consumed after the histogram update (the work-item lanes fetch their own copy)
+        if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
+        if (p.size_reward && e.step_no == 1) env_max_int = p.task_meta[task].env_max_int;
     }
     int incmax = 0;
     bool decd = false;
     const bool changed = active && ch.idx >= 0 && !(p.debug & 1);
-    resolve_changes<GS>(G, p, sh.ws[wave], changed, env, task, ch.idx, syn_a, syn_b, e.max_int, incmax, decd);
+    resolve_changes<GS, false>(G, p, sh.ws[wave], changed, env, task, ch, e.max_int, incmax, decd);
+    size_new = e.prev_size;
+    if (active && ch.idx >= 0) {
+        size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
+        need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
+    }
     int mi = e.max_int;
     bool rescan = false;
     if (changed) {
@@ -511,8 +531,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     if (active) {
         o = finish_step(p, e, env_max_int, size_new, mi);
         do_reset = o.done && p.autoreset;
-        if (do_reset && meta == nullptr) {
-            task = p.env_task[env];
+        if (do_reset) {
             meta = p.task_meta + task;
             has_start = meta->has_start != 0;
         }
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
     for (long long t = 0; t < T; t++) {
         CellChange ch;
         ch.idx = -1; ch.old_val = ch.new_val = 0;
-        int size_new = 0, syn_a = 0, syn_b = 0;
+        int size_new = 0;
         bool need = false;
         if (active) {
             e.step_no = min(e.step_no + 1, 65535);
@@ -582,15 +601,13 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
             ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, action);
             int start_val = 0;
             if (ch.idx >= 0 && has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
-            syn_a = ch.old_val - start_val;
-            syn_b = ch.new_val - start_val;
             size_new = e.prev_size + syn_size_delta(ch, start_val);
             need = size_new != e.prev_size;
         }
         int incmax = 0;
         bool decd = false;
         const bool changed = active && ch.idx >= 0;
-        resolve_changes<GS>(G, p, sh.ws[wave], changed, env, task, ch.idx, syn_a, syn_b, e.max_int, incmax, decd);
+        resolve_changes<GS, true>(G, p, sh.ws[wave], changed, env, task, ch, e.max_int, incmax, decd);
         int mi = e.max_int;
         bool rescan = false;
         if (changed) {

@@ -114,10 +114,10 @@ typedef struct igw_config {
  *   0  f64 init_pose[5]   x, y, z, yaw, pitch (GridWorld.initial_position/rotation)
  *   40 i16 target_size    _synthetic_task.target_size
  *   42 i16 env_max_int    GridWorld.max_int at reset (user task on the starting grid)
- *   44 i8  bbox[4][4]     per rotation xmin, xmax, zmin, zmax of the synthetic target
- *   60 i8  inv_init[6]    inventory at reset (20 - blocks of that colour in the start grid)
- *   66 u8  has_start      starting grid not empty
- *   67 ..  zero
+ *   44 u8  has_start      starting grid not empty
+ *   48 i8  bbox[4][4]     per rotation xmin, xmax, zmin, zmax of the synthetic target
+ *   64 i8  inv_init[6]    inventory at reset (20 - blocks of that colour in the start grid)
+ *   70 ..  zero
  */
 typedef struct igw_buffers {
     /* state */
