@@ -97,6 +97,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--debug-flags', type=int, default=0, help='timing-only ablations (results invalid)')
+    ap.add_argument('--mode', choices=['walking', 'flying'], default='walking',
+                    help='walking = BASELINE configs[2] (headline); flying = configs[3]')
     args = ap.parse_args()
 
     from gridworld_amd import VecGridWorld, dist as gdist, workloads
@@ -110,18 +112,37 @@ def main():
     N, K, W = args.envs_per_gpu, args.steps, args.warmup
     env_offset = rank * N  # rank-offset RNG streams / task seeds
 
-    env = VecGridWorld(N, device=device, action_space='walking', size_reward=False, max_steps=250,
+    flying = args.mode == 'flying'
+    env = VecGridWorld(N, device=device, action_space=args.mode, size_reward=False, max_steps=250,
                        autoreset=True, lanes_per_env=args.lanes_per_env, debug_flags=args.debug_flags)
     env.set_tasks(workloads.rt20(N, seed=args.seed + rank, device=device))
     env.reset()
     # actions for warmup + timed steps are generated on the device before the clock starts
-    chunk = 256
-    actions = [env.fill_actions(min(chunk, W + K - t0), seed=args.seed, t0=t0, env_offset=env_offset)
-               for t0 in range(0, W + K, chunk)]
-    act = lambda t: actions[t // chunk][t % chunk]  # noqa: E731
+    if flying:
+        if args.no_fused is False:
+            args.no_fused = True  # the fused rollout kernel is walking-only
+        g = torch.Generator(device=device)
+        g.manual_seed(args.seed + 7919 * rank)
+        mv = torch.rand((W + K, N, 3), generator=g, device=device) * 2 - 1      # movement ~ U(-1, 1)^3
+        cam = torch.rand((W + K, N, 2), generator=g, device=device) * 10 - 5    # camera ~ U(-5, 5)^2
+        inv = torch.randint(0, 7, (W + K, N), generator=g, device=device, dtype=torch.int32)
+        plc = torch.randint(0, 3, (W + K, N), generator=g, device=device, dtype=torch.int32)
+        import ctypes as C
+        from gridworld_amd import _lib as L
+
+        def step(t):
+            L.check(env.lib.igw_step_flying(env.ctx, mv[t].data_ptr(), cam[t].data_ptr(), inv[t].data_ptr(),
+                                            plc[t].data_ptr(), env._stream()), 'igw_step_flying')
+    else:
+        chunk = 256
+        actions = [env.fill_actions(min(chunk, W + K - t0), seed=args.seed, t0=t0, env_offset=env_offset)
+                   for t0 in range(0, W + K, chunk)]
+
+        def step(t):
+            env.step_walking_ptr(actions[t // chunk][t % chunk])
 
     for t in range(W):
-        env.step_walking_ptr(act(t))
+        step(t)
     torch.cuda.synchronize(device)
     st0 = env.stats()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -130,7 +151,7 @@ def main():
     t_start = time.perf_counter()
     ev0.record()
     for t in range(W, W + K):
-        env.step_walking_ptr(act(t))
+        step(t)
     ev1.record()
     torch.cuda.synchronize(device)
     gdist.barrier(device)
@@ -158,7 +179,7 @@ def main():
     lanes = env.cfg.lanes_per_env or 4
     p = (st1['changed'] - st0['changed']) / float(N * K)
     resets = st1['resets'] - st0['resets']
-    bytes_per_step = BYTES_BASE + BYTES_CHANGED * p
+    bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4
     achieved = N * bytes_per_step / (kernel_ms * 1e-3) / 1e9
     traffic = load_traffic()
     out = {
@@ -174,20 +195,25 @@ def main():
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': 'configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block '
-                               'targets (rt20), full maximal_intersection reward, uniform random actions, '
-                               'auto-reset at done (max_steps=250)',
+        'config': {'workload': ('configs[3]: 65,536 parallel envs per GPU, flying action space (continuous movement / '
+                                'camera Box), random 20-block targets (rt20), uniform random actions, auto-reset at '
+                                'done (max_steps=250)') if flying else
+                               ('configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block '
+                                'targets (rt20), full maximal_intersection reward, uniform random actions, '
+                                'auto-reset at done (max_steps=250)'),
                    'envs_per_gpu': N, 'total_envs': N * world, 'lanes_per_env': lanes,
                    'launches_per_step': 1, 'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None if traffic is None else traffic.get('hbm_bytes_per_launch'),
-                     'kernel': 'igw::step_kernel<%d, 0>' % lanes, 'kernel_avg_ms': kernel_ms,
+                     'kernel': 'igw::step_kernel<%d, %d>' % (lanes, 1 if flying else 0), 'kernel_avg_ms': kernel_ms,
                      'algorithmic_bytes_per_env_step': bytes_per_step,
                      'algorithmic_bytes_per_launch': N * bytes_per_step},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if flying:
+        out['roofline']['traffic'] = None  # the committed PMC profile is for the walking kernel
+    if world == 1 and not args.no_cpu_baseline and not flying:
         out['cpu_baseline'] = cpu_baseline(args.seed)
     print(json.dumps(out))
 

@@ -17,12 +17,13 @@ OCC_WORDS = 36
 HIST_ROW = 512
 STAT_STRIPES = 64
 STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS = 0, 1, 2, 3
-WALKING_DISCRETE, FLYING = 0, 1
+WALKING_DISCRETE, FLYING, WALKING_DICT = 0, 1, 2
 RESET_KEEP_SIZE = 1
 
 # every symbol include/igw.h declares (checked by tests/test_abi.py)
 EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy',
            'igw_bind_buffers', 'igw_prepare_tasks', 'igw_reset', 'igw_step_walking', 'igw_step_flying',
+           'igw_step_walking_dict',
            'igw_rollout_walking', 'igw_fill_actions_walking', 'igw_task_eval']
 
 
@@ -73,6 +74,7 @@ def load(build_if_missing=True):
     L.igw_reset.argtypes = [vp, vp, i32, vp]
     L.igw_step_walking.argtypes = [vp, vp, vp]
     L.igw_step_flying.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.igw_step_walking_dict.argtypes = [vp, vp, vp, vp]
     L.igw_rollout_walking.argtypes = [vp, i64, u64, i64, i64, vp]
     L.igw_fill_actions_walking.argtypes = [vp, vp, i64, i64, u64, i64, vp]
     L.igw_task_eval.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -21,7 +21,7 @@
 
 namespace igw {
 
-enum { MODE_WALK = 0, MODE_FLY = 1 };
+enum { MODE_WALK = 0, MODE_FLY = 1, MODE_WALK_DICT = 2 };
 
 struct ActIn {
     const int32_t* actions;
@@ -29,6 +29,7 @@ struct ActIn {
     const float* camera;
     const int32_t* inventory;
     const int32_t* placement;
+    const uint8_t* buttons;  // walking Dict: [N][8] forward, back, left, right, jump, attack, use, hotbar
 };
 
 struct StepOut {
@@ -492,6 +493,15 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
         e.step_no = min(e.step_no + 1, 65535);  // env.py:276
         if (MODE == MODE_WALK) {
             ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, a.actions[env]);
+        } else if (MODE == MODE_WALK_DICT) {  // parse_walking_action, core/world.py:396-414
+            const uint2 bw = *reinterpret_cast<const uint2*>(a.buttons + 8 * (size_t)env);
+            const float* cam = a.camera + 2 * (size_t)env;
+            const bool fwd = bw.x & 0xffu, back = bw.x & 0xff00u, left = bw.x & 0xff0000u, right = bw.x & 0xff000000u;
+            const bool jump = bw.y & 0xffu, attack = bw.y & 0xff00u, use = bw.y & 0xff0000u;
+            const int hotbar = (int)(bw.y >> 24);
+            const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
+            ch = world_step<GS, MODE_WALK_DICT>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar,
+                                                (double)cam[0], (double)cam[1], attack, use);
         } else {  // parse_flying_action, core/world.py:416-432
             const float* mv = a.movement + 3 * (size_t)env;
             const float* cam = a.camera + 2 * (size_t)env;
@@ -923,7 +933,8 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     *out = nullptr;
     if (cfg->num_envs < 1 || cfg->num_tasks < 1) return fail(IGW_ERR_INVALID, "igw_create: num_envs / num_tasks must be >= 1");
     if (cfg->max_steps < 1 || cfg->max_steps > 65534) return fail(IGW_ERR_INVALID, "igw_create: max_steps must be in 1..65534");
-    if (cfg->action_space != IGW_WALKING_DISCRETE && cfg->action_space != IGW_FLYING)
+    if (cfg->action_space != IGW_WALKING_DISCRETE && cfg->action_space != IGW_FLYING &&
+        cfg->action_space != IGW_WALKING_DICT)
         return fail(IGW_ERR_INVALID, "igw_create: unknown action_space");
     int gs = cfg->lanes_per_env ? cfg->lanes_per_env : IGW_DEFAULT_LANES_PER_ENV;
     if (gs != 64 && gs != 32 && gs != 16 && gs != 8 && gs != 4 && gs != 2 && gs != 1)
@@ -1038,7 +1049,7 @@ int igw_step_walking(igw_ctx* ctx, const int32_t* actions, void* stream) {
     CHECK_CTX("igw_step_walking");
     if (ctx->cfg.action_space != IGW_WALKING_DISCRETE) return fail(IGW_ERR_INVALID, "igw_step_walking: context was created for another action space");
     if (!actions) return fail(IGW_ERR_INVALID, "igw_step_walking: actions is null");
-    ActIn a = {actions, nullptr, nullptr, nullptr, nullptr};
+    ActIn a = {actions, nullptr, nullptr, nullptr, nullptr, nullptr};
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_WALK>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, a));
     HIP_TRY(hipGetLastError());
@@ -1050,8 +1061,20 @@ int igw_step_flying(igw_ctx* ctx, const float* movement, const float* camera, co
     CHECK_CTX("igw_step_flying");
     if (ctx->cfg.action_space != IGW_FLYING) return fail(IGW_ERR_INVALID, "igw_step_flying: context was created for another action space");
     if (!movement || !camera || !inventory || !placement) return fail(IGW_ERR_INVALID, "igw_step_flying: an action buffer is null");
-    ActIn a = {nullptr, movement, camera, inventory, placement};
+    ActIn a = {nullptr, movement, camera, inventory, placement, nullptr};
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_FLY>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
+                                            (hipStream_t)stream, ctx->kp, a));
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_step_walking_dict(igw_ctx* ctx, const uint8_t* buttons, const float* camera, void* stream) {
+    CHECK_CTX("igw_step_walking_dict");
+    if (ctx->cfg.action_space != IGW_WALKING_DICT) return fail(IGW_ERR_INVALID, "igw_step_walking_dict: context was created for another action space");
+    if (!buttons || !camera) return fail(IGW_ERR_INVALID, "igw_step_walking_dict: an action buffer is null");
+    if ((uintptr_t)buttons & 7) return fail(IGW_ERR_INVALID, "igw_step_walking_dict: buttons must be 8-byte aligned");
+    ActIn a = {nullptr, nullptr, camera, nullptr, nullptr, buttons};
+    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_WALK_DICT>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, a));
     HIP_TRY(hipGetLastError());
     return IGW_OK;

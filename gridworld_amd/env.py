@@ -25,15 +25,13 @@ class GridWorld:
         if render and not fake:
             raise NotImplementedError('the renderer is out of scope of the MI355X step path; pass render=False '
                                       "(or use 'IGLUGridworldVector-v0')")
-        if action_space == 'walking' and not discretize:
-            raise NotImplementedError('only discretize=True (Discrete(18)) walking is on the device path')
         self.vector_state, self.target_in_obs, self.fake, self.do_render = vector_state, target_in_obs, fake, render
         self.render_size, self.name = render_size, name
         self.max_steps, self.select_and_place, self.discretize = max_steps, select_and_place, discretize
         self.action_space_type = action_space
         self._vec = VecGridWorld(1, device=device, action_space=action_space, select_and_place=select_and_place,
                                  size_reward=size_reward, max_steps=max_steps,
-                                 right_placement_scale=right_placement_scale,
+                                 right_placement_scale=right_placement_scale, discretize=discretize,
                                  wrong_placement_scale=wrong_placement_scale, num_tasks=1)
         self._task = None
         self._task_generator = None
@@ -41,8 +39,14 @@ class GridWorld:
         self.initial_position = (0, 0, 0)
         self.initial_rotation = (0, 0)
         self.starting_grid = None
-        if action_space == 'walking':
+        if action_space == 'walking' and discretize:
             self.action_space = spaces.Discrete(18)
+        elif action_space == 'walking':  # env.py:60-70
+            self.action_space = spaces.Dict({
+                'forward': spaces.Discrete(2), 'back': spaces.Discrete(2), 'left': spaces.Discrete(2),
+                'right': spaces.Discrete(2), 'jump': spaces.Discrete(2), 'attack': spaces.Discrete(2),
+                'use': spaces.Discrete(2), 'camera': spaces.Box(low=-5, high=5, shape=(2,)),
+                'hotbar': spaces.Discrete(7)})
         elif action_space == 'flying':
             self.action_space = spaces.Dict({
                 'movement': spaces.Box(low=-1, high=1, shape=(3,), dtype=np.float32),
@@ -153,6 +157,12 @@ class GridWorld:
             a = {'movement': np.asarray(action['movement'], np.float32)[None],
                  'camera': np.asarray(action['camera'], np.float32)[None],
                  'inventory': np.array([inv], np.int32), 'placement': np.array([int(action['placement'])], np.int32)}
+        elif not self.discretize:
+            hot = int(action['hotbar'])
+            if hot < 0 or hot > 6:
+                raise ValueError(f'Bad inventory id: {hot}')
+            b = [int(bool(action[k])) for k in ('forward', 'back', 'left', 'right', 'jump', 'attack', 'use')] + [hot]
+            a = {'buttons': np.array([b], np.uint8), 'camera': np.asarray(action['camera'], np.float32)[None]}
         else:
             a = torch.tensor([int(action)], dtype=torch.int32)
         self._vec.step(a)

@@ -40,13 +40,12 @@ class VecGridWorld:
             raise L.IgwError('VecGridWorld needs a HIP device (no CPU fallback)')
         if action_space not in ('walking', 'flying'):
             raise ValueError(f'unknown action_space {action_space!r}')
-        if action_space == 'walking' and not discretize:
-            raise NotImplementedError('only the Discrete(18) walking action space is on the device path')
         self.lib = L.load()
         self.device = torch.device(device)
         self.num_envs = int(num_envs)
         self.num_tasks = int(num_tasks or num_envs)
         self.flying = action_space == 'flying'
+        self.walk_dict = action_space == 'walking' and not discretize
         self.max_steps = int(max_steps)
         self.autoreset = bool(autoreset)
         N, T, dev = self.num_envs, self.num_tasks, self.device
@@ -69,7 +68,8 @@ class VecGridWorld:
         # Agent.__init__ (core/world.py:12-29): time_int_steps = 2, active_block = BLUE, inventory 20
         self.agent_buf[:, 56:62] = 20
         self.agent_buf[:, 62] = 1 << 2  # u16 pack: time_int_steps code 0 (= 2), active_block 1, target_size 0
-        self.cfg = L.Config(dev.index or 0, N, T, L.FLYING if self.flying else L.WALKING_DISCRETE,
+        self.cfg = L.Config(dev.index or 0, N, T,
+                            L.FLYING if self.flying else L.WALKING_DICT if self.walk_dict else L.WALKING_DISCRETE,
                             int(select_and_place), int(size_reward), self.max_steps, int(autoreset),
                             float(right_placement_scale), float(wrong_placement_scale), int(lanes_per_env),
                             int(debug_flags))
@@ -146,11 +146,24 @@ class VecGridWorld:
         return self.obs()
 
     def step(self, actions):
-        """walking: int32 tensor [N]; flying: dict(movement f32[N,3], camera f32[N,2], inventory i32[N],
-        placement i32[N]).  Returns (obs, reward, done, info) of tensors living in HBM."""
+        """walking: int32 tensor [N]; walking with discretize=False: dict(buttons u8[N,8] = forward, back,
+        left, right, jump, attack, use, hotbar -- or those eight keys separately -- and camera f32[N,2]);
+        flying: dict(movement f32[N,3], camera f32[N,2], inventory i32[N], placement i32[N]).
+        Returns (obs, reward, done, info) of tensors living in HBM."""
         self._need_tasks()
         dev = self.device
-        if self.flying:
+        if self.walk_dict:
+            if 'buttons' in actions:
+                b = torch.as_tensor(actions['buttons'], device=dev).to(torch.uint8).reshape(self.num_envs, 8).contiguous()
+            else:  # the reference's Dict keys (env.py:60-70), one array per key
+                b = torch.stack([torch.as_tensor(np.asarray(actions[k]), device=dev).to(torch.uint8).reshape(-1)
+                                 for k in ('forward', 'back', 'left', 'right', 'jump', 'attack', 'use', 'hotbar')],
+                                dim=1).contiguous()
+            cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).reshape(self.num_envs, 2).contiguous()
+            L.check(self.lib.igw_step_walking_dict(self.ctx, b.data_ptr(), cam.data_ptr(), self._stream()),
+                    'igw_step_walking_dict')
+            self._act_keep = (b, cam)
+        elif self.flying:
             mv = torch.as_tensor(actions['movement'], device=dev).to(torch.float32).contiguous()
             cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).contiguous()
             inv = torch.as_tensor(actions['inventory'], device=dev).to(torch.int32).contiguous()

@@ -12,6 +12,7 @@
  *   igw_step_walking   <- GridWorld.step (env.py:268-303) with World.step /
  *                         parse_walking_discrete_action (core/world.py:360-394, 434-456)
  *   igw_step_flying    <- same with parse_flying_action (core/world.py:416-432)
+ *   igw_step_walking_dict <- same with parse_walking_action, discretize=False (core/world.py:396-414)
  *   igw_task_eval      <- Task.maximal_intersection / argmax_intersection
  *                         (tasks/task.py:121-161)
  *   igw_rollout_walking<- the loop of examples/run_env.py:18-26 fused on device
@@ -72,7 +73,8 @@ enum igw_status {
 
 enum igw_action_space {
     IGW_WALKING_DISCRETE = 0, /* Discrete(18), create_env default (env.py:333-338) */
-    IGW_FLYING = 1            /* Dict(movement, camera, inventory, placement) (env.py:71-78) */
+    IGW_FLYING = 1,           /* Dict(movement, camera, inventory, placement) (env.py:71-78) */
+    IGW_WALKING_DICT = 2      /* discretize=False: Dict of buttons + continuous camera (env.py:60-70) */
 };
 
 /* create_env kwargs that reach the step path (env.py:333-350) */
@@ -166,6 +168,10 @@ int igw_step_walking(igw_ctx* ctx, const int32_t* actions /* [N] in 0..17 */, vo
 int igw_step_flying(igw_ctx* ctx, const float* movement /* [N][3] */, const float* camera /* [N][2] */,
                     const int32_t* inventory /* [N] 0..6 */, const int32_t* placement /* [N] 0..2 */,
                     void* stream);
+
+/* walking with discretize=False (parse_walking_action, core/world.py:396-414): buttons uint8 [N][8] =
+ * forward, back, left, right, jump, attack, use, hotbar(0..6), 8-byte aligned; camera float [N][2] */
+int igw_step_walking_dict(igw_ctx* ctx, const uint8_t* buttons, const float* camera, void* stream);
 
 /* T fused walking steps per env, actions = uniform Discrete(18) from a counter RNG keyed by
  * (seed, env_offset + env, t) for t = t0 .. t0+T-1; auto-reset on done regardless of cfg.autoreset. */

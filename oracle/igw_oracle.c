@@ -560,6 +560,21 @@ void igo_step_walking(igo_env* e, int action) {
     finish_step(e);
 }
 
+/* core/world.py:396-414 (discretize=False): buttons = forward, back, left, right, jump, attack, use, hotbar */
+void igo_step_walking_dict(igo_env* e, const uint8_t* b, const double* camera) {
+    double strafe[2] = {0, 0};
+    if (b[0]) strafe[0] += -1;
+    if (b[1]) strafe[0] += 1;
+    if (b[2]) strafe[1] += -1;
+    if (b[3]) strafe[1] += 1;
+    double jump = b[4] ? 1 : 0;   /* int(action['jump']) */
+    int inventory = b[7];         /* hotbar 0 -> None */
+    int remove = b[5] != 0, add = b[6] != 0;
+    e->step_no += 1;
+    world_step(e, strafe, jump, inventory, camera, remove, add);
+    finish_step(e);
+}
+
 /* core/world.py:416-432 */
 void igo_step_flying(igo_env* e, const double* movement, const double* camera, int inventory,
                      int placement) {
@@ -616,7 +631,8 @@ static inline int rng_action18(uint64_t seed, uint64_t env, uint64_t t) {
 }
 
 typedef struct {
-    int kind; /* 0 walking step, 1 flying step, 2 walking rollout */
+    int kind; /* 0 walking step, 1 flying step, 2 walking rollout, 3 walking Dict step */
+    const uint8_t* buttons;
     igo_env** envs;
     int64_t lo, hi;
     const int32_t* actions;
@@ -645,6 +661,9 @@ static void* job_run(void* arg) {
         }
         if (j->kind == 0) {
             igo_step_walking(e, j->actions[i]);
+        } else if (j->kind == 3) {
+            double cam[2] = {j->camera[2 * i], j->camera[2 * i + 1]};
+            igo_step_walking_dict(e, j->buttons + 8 * i, cam);
         } else {
             double mv[3] = {j->movement[3 * i], j->movement[3 * i + 1], j->movement[3 * i + 2]};
             double cam[2] = {j->camera[2 * i], j->camera[2 * i + 1]};
@@ -693,6 +712,14 @@ void igo_batch_step_flying(igo_env** envs, int64_t n, const float* movement, con
     memset(&j, 0, sizeof(j));
     j.kind = 1; j.envs = envs; j.movement = movement; j.camera = camera; j.inventory = inventory;
     j.placement = placement; j.autoreset = autoreset; j.out = out;
+    run_jobs(&j, n, nthreads, NULL, NULL);
+}
+
+void igo_batch_step_walking_dict(igo_env** envs, int64_t n, const uint8_t* buttons, const float* camera,
+                                 int autoreset, int nthreads, const igo_batch_out* out) {
+    job_t j;
+    memset(&j, 0, sizeof(j));
+    j.kind = 3; j.envs = envs; j.buttons = buttons; j.camera = camera; j.autoreset = autoreset; j.out = out;
     run_jobs(&j, n, nthreads, NULL, NULL);
 }
 

@@ -97,6 +97,9 @@ def lib():
         L.igo_reset.argtypes = [C.c_void_p]
         L.igo_step_walking.argtypes = [C.c_void_p, C.c_int]
         L.igo_step_flying.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.igo_step_walking_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.igo_batch_step_walking_dict.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                  C.POINTER(BatchOut)]
         L.igo_get_obs.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.igo_get_reward.restype = C.c_double
         L.igo_get_reward.argtypes = [C.c_void_p]
@@ -139,8 +142,9 @@ class OracleEnv:
     """One reference-semantics env (gym.make('IGLUGridworld-v0', vector_state=True, render=False))."""
 
     def __init__(self, action_space='walking', select_and_place=True, size_reward=True, max_steps=250,
-                 right_placement_scale=1., wrong_placement_scale=0.1):
+                 right_placement_scale=1., wrong_placement_scale=0.1, discretize=True):
         self.flying = action_space == 'flying'
+        self.discretize = discretize
         self.cfg = Config(FLYING if self.flying else WALKING, int(select_and_place), int(size_reward),
                           int(max_steps), float(right_placement_scale), float(wrong_placement_scale))
         self.h = C.c_void_p(lib().igo_create(C.byref(self.cfg)))
@@ -166,7 +170,11 @@ class OracleEnv:
         return self.obs()
 
     def step(self, action):
-        if self.flying:
+        if isinstance(action, dict) and 'buttons' in action:  # walking, discretize=False
+            b = np.ascontiguousarray(action['buttons'], dtype=np.uint8)
+            cam = np.ascontiguousarray(action['camera'], dtype=np.float64)
+            lib().igo_step_walking_dict(self.h, _p(b), _p(cam))
+        elif self.flying:
             mv = np.ascontiguousarray(action['movement'], dtype=np.float64)
             cam = np.ascontiguousarray(action['camera'], dtype=np.float64)
             lib().igo_step_flying(self.h, _p(mv), _p(cam), int(action['inventory']),
@@ -256,6 +264,12 @@ class OracleBatch:
         pl = np.ascontiguousarray(placement, dtype=np.int32)
         lib().igo_batch_step_flying(self.handles, self.n, _p(mv), _p(cam), _p(inv), _p(pl),
                                     int(autoreset), nthreads, C.byref(self._out))
+
+    def step_walking_dict(self, buttons, camera, autoreset=False, nthreads=1):
+        b = np.ascontiguousarray(buttons, dtype=np.uint8)
+        cam = np.ascontiguousarray(camera, dtype=np.float32)
+        lib().igo_batch_step_walking_dict(self.handles, self.n, _p(b), _p(cam), int(autoreset), nthreads,
+                                          C.byref(self._out))
 
     def rollout_walking(self, T, seed, env_offset=0, autoreset=True, nthreads=1):
         changed = np.zeros(1, np.int64)

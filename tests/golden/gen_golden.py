@@ -29,12 +29,15 @@ def starts_to_dense(starts):
 
 
 def save(name, kwargs, targets, starts, actions, ref, task_kwargs=None, init_pose=None):
-    flying = isinstance(actions, dict)
+    walkdict = isinstance(actions, dict) and 'buttons' in actions
+    flying = isinstance(actions, dict) and not walkdict
     d = dict(kwargs=json.dumps(kwargs), task_kwargs=json.dumps(task_kwargs or {}),
              targets=np.asarray(targets, np.int8), starts=starts_to_dense(starts))
     if init_pose is not None:
         d['init_pose'] = np.asarray(init_pose, np.float64)
-    if flying:
+    if walkdict:
+        d.update(act_buttons=actions['buttons'].astype(np.uint8), act_camera=actions['camera'].astype(np.float32))
+    elif flying:
         d.update(act_movement=actions['movement'].astype(np.float32),
                  act_camera=actions['camera'].astype(np.float32),
                  act_inventory=actions['inventory'].astype(np.int32),
@@ -218,6 +221,18 @@ def main():
     kw = dict(size_reward=False)
     save('s5_init_pose', kw, tg, [[]] * E, acts,
          H.run_batch(kw, tg, [[]] * E, acts, init_pose=poses), init_pose=poses)
+
+    # S8 -- walking with discretize=False (Dict of buttons + continuous camera, env.py:60-70)
+    rng = np.random.RandomState(808)
+    E, T = 12, 400
+    tg = np.stack([rt20(rng) for _ in range(8)] + [cdm_with_start(rng, goals, names)[0] for _ in range(4)])
+    b = (rng.rand(E, T, 8) < 0.25).astype(np.uint8)
+    b[:, :, 7] = rng.randint(0, 7, size=(E, T)) * (rng.rand(E, T) < 0.3)
+    cam = rng.uniform(-5, 5, size=(E, T, 2)).astype(np.float32)
+    cam[:, ::7] = 0.0  # steps without camera motion
+    kw = dict(size_reward=False, discretize=False)
+    wd = dict(buttons=b, camera=cam)
+    save('s8_walk_dict', kw, tg, [[]] * E, wd, H.run_batch(kw, tg, [[]] * E, wd))
 
     # S6 -- pure Task vectors: admissible sets, rotations, maximal / argmax intersection
     rng = np.random.RandomState(606)

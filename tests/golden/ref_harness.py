@@ -64,6 +64,13 @@ def flying_action(move, cam, inv, place):
             'inventory': int(inv), 'placement': int(place)}
 
 
+def walking_dict_action(buttons, cam):
+    """discretize=False walking action (env.py:60-70); camera as Python floats widened from float32."""
+    b = [int(v) for v in buttons]
+    return {'forward': b[0], 'back': b[1], 'left': b[2], 'right': b[3], 'jump': b[4], 'attack': b[5],
+            'use': b[6], 'hotbar': b[7], 'camera': [float(np.float32(v)) for v in cam]}
+
+
 def run_batch(kwargs, targets, starts, actions, reset_on_done=True, task_kwargs=None,
               init_pose=None):
     """Runs E independent reference envs for T steps each.
@@ -77,9 +84,10 @@ def run_batch(kwargs, targets, starts, actions, reset_on_done=True, task_kwargs=
     Returns a dict of numpy arrays.
     """
     gym, Task, Tasks = load_reference()
-    flying = isinstance(actions, dict)
+    walkdict = isinstance(actions, dict) and 'buttons' in actions
+    flying = isinstance(actions, dict) and not walkdict
     E = len(targets)
-    T = (actions['inventory'] if flying else actions).shape[1]
+    T = (actions['buttons'] if walkdict else actions['inventory'] if flying else actions).shape[1]
     out = dict(
         agentPos=np.zeros((E, T, 5), np.float32), inventory=np.zeros((E, T, 6), np.float32),
         compass=np.zeros((E, T), np.float32), reward=np.zeros((E, T), np.float64),
@@ -112,7 +120,9 @@ def run_batch(kwargs, targets, starts, actions, reset_on_done=True, task_kwargs=
             if done and reset_on_done:
                 env.reset()
                 out['reset_before'][e, t] = 1
-            if flying:
+            if walkdict:
+                a = walking_dict_action(actions['buttons'][e, t], actions['camera'][e, t])
+            elif flying:
                 a = flying_action(actions['movement'][e, t], actions['camera'][e, t],
                                   actions['inventory'][e, t], actions['placement'][e, t])
             else:

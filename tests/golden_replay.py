@@ -21,6 +21,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 WALK_FIXTURES = ['s1_walk_dummy', 's1_walk_dummy_sizereward', 's2_walk_cdm', 's2_walk_cdm_sizereward',
                  's3_walk_rt20', 's5_scripted', 's5_scripted_scales', 's5_scripted_leak', 's5_init_pose']
 FLY_FIXTURES = ['s4_fly_rt20', 's4_fly_cdm']
+DICT_FIXTURES = ['s8_walk_dict']
 
 
 def load_fixture(name):
@@ -30,6 +31,7 @@ def load_fixture(name):
     fx['task_kwargs'] = json.loads(str(fx['task_kwargs']))
     fx['name'] = name
     fx['flying'] = 'act_movement' in fx
+    fx['walkdict'] = 'act_buttons' in fx
     return fx
 
 
@@ -64,7 +66,9 @@ def replay(fx, driver, check_internal=True, max_steps=None, float_bits=True):
         if rb.any():
             driver.reset(rb)
             grid[rb] = starts.reshape(E, -1)[rb]
-        if fx['flying']:
+        if fx['walkdict']:
+            driver.step_walking_dict(fx['act_buttons'][:, t], fx['act_camera'][:, t])
+        elif fx['flying']:
             driver.step_flying(fx['act_movement'][:, t], fx['act_camera'][:, t], fx['act_inventory'][:, t],
                                fx['act_placement'][:, t])
         else:
@@ -121,6 +125,9 @@ class OracleDriver:
 
     def step_flying(self, mv, cam, inv, place):
         self.b.step_flying(mv, cam, inv, place)
+
+    def step_walking_dict(self, buttons, cam):
+        self.b.step_walking_dict(buttons, cam)
 
     def outputs(self):
         b = self.b

@@ -32,6 +32,9 @@ class HipDriver:
         self.env.step(dict(movement=np.asarray(mv, np.float32), camera=np.asarray(cam, np.float32),
                            inventory=np.asarray(inv, np.int32), placement=np.asarray(place, np.int32)))
 
+    def step_walking_dict(self, buttons, cam):
+        self.env.step(dict(buttons=np.asarray(buttons, np.uint8), camera=np.asarray(cam, np.float32)))
+
     def outputs(self):
         e = self.env
         torch.cuda.synchronize()

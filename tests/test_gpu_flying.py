@@ -28,6 +28,45 @@ def test_flying_fixture_reference_trig(name):
     print(f'{name}: {n_bits} of {len(fin)} envs end with a last-bit float64 difference vs glibc')
 
 
+def test_walking_dict_fixture_reference_trig():
+    """discretize=False walking (buttons + continuous camera): same contract as flying vs the reference."""
+    from hip_driver import HipDriver
+    fx = GR.load_fixture('s8_walk_dict')
+    assert GR.replay(fx, HipDriver(fx), check_internal=False) == fx['done'].size
+
+
+@pytest.mark.parametrize('gs', [0, 64, 1])
+def test_walking_dict_vs_oracle_device_trig(gs):
+    from gridworld_amd import VecGridWorld, workloads
+    from oracle import oracle as O
+    n, T = 512, 200
+    kw = dict(size_reward=False, discretize=False, max_steps=80)
+    tg = workloads.rt20(n, seed=29).numpy()
+    O.use_device_trig(True)
+    try:
+        env = VecGridWorld(n, autoreset=True, lanes_per_env=gs, **kw)
+        env.set_tasks(tg)
+        env.reset()
+        ob = O.OracleBatch(n, **kw)
+        ob.set_tasks(tg)
+        ob.reset()
+        rng = np.random.RandomState(6)
+        for t in range(T):
+            b = (rng.rand(n, 8) < 0.3).astype(np.uint8)
+            b[:, 7] = rng.randint(0, 7, size=n) * (rng.rand(n) < 0.3)
+            cam = rng.uniform(-5, 5, size=(n, 2)).astype(np.float32)
+            env.step(dict(buttons=b, camera=cam))
+            ob.step_walking_dict(b, cam, autoreset=True, nthreads=8)
+            if t % 20 == 19 or t == T - 1:
+                torch.cuda.synchronize()
+                assert np.array_equal(env.done.cpu().numpy(), ob.done), t
+                assert np.array_equal(env.reward.cpu().numpy(), ob.reward), t
+                assert np.array_equal(env.grid.cpu().numpy().reshape(n, -1), ob.grid), t
+                assert np.array_equal(env.internals().view(np.uint64), ob.internals().view(np.uint64)), t
+    finally:
+        O.use_device_trig(False)
+
+
 def _fly_actions(rng, n):
     return dict(movement=rng.uniform(-1, 1, size=(n, 3)).astype(np.float32),
                 camera=rng.uniform(-5, 5, size=(n, 2)).astype(np.float32),

@@ -7,7 +7,7 @@ import golden_replay as GR
 from oracle import oracle as O
 
 
-@pytest.mark.parametrize('name', GR.WALK_FIXTURES + GR.FLY_FIXTURES)
+@pytest.mark.parametrize('name', GR.WALK_FIXTURES + GR.FLY_FIXTURES + GR.DICT_FIXTURES)
 def test_oracle_replays_fixture(name):
     fx = GR.load_fixture(name)
     n = GR.replay(fx, GR.OracleDriver(fx))
