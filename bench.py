@@ -107,7 +107,8 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    device = torch.device('cuda', local_rank)
+    # one process per GPU; IGW_SHARE_GPU=1 lets several ranks share one device (CI on a 1-GPU box, gloo)
+    device = torch.device('cuda', 0 if os.environ.get('IGW_SHARE_GPU') else local_rank)
     torch.cuda.set_device(device)
     N, K, W = args.envs_per_gpu, args.steps, args.warmup
     env_offset = rank * N  # rank-offset RNG streams / task seeds

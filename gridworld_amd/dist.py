@@ -20,7 +20,7 @@ def init(backend=None):
     rank, local_rank, world = env_info()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('IGW_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
@@ -37,9 +37,16 @@ def shard_envs(total_envs, rank, world):
     return lo, hi
 
 
+def _comm_device(device):
+    """Tensors for the control-plane collectives live where the backend can reduce them."""
+    if dist.is_initialized() and dist.get_backend() == 'nccl' and device is not None:
+        return device
+    return torch.device('cpu')
+
+
 def barrier(device=None):
     if dist.is_initialized():
-        if device is not None and device.type == 'cuda':
+        if device is not None and device.type == 'cuda' and dist.get_backend() == 'nccl':
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
@@ -49,7 +56,7 @@ def reduce_window(steps, seconds, device=None):
     """(total env-steps over all ranks, max elapsed seconds over ranks)."""
     if not dist.is_initialized():
         return int(steps), float(seconds)
-    dev = device if device is not None else torch.device('cpu')
+    dev = _comm_device(device)
     s = torch.tensor([int(steps)], dtype=torch.int64, device=dev)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=dev)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
@@ -61,7 +68,7 @@ def gather_counts(value, device=None):
     """all_gather of one int64 per rank (e.g. per-rank step counters)."""
     if not dist.is_initialized():
         return [int(value)]
-    dev = device if device is not None else torch.device('cpu')
+    dev = _comm_device(device)
     mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)

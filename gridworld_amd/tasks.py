@@ -129,6 +129,68 @@ class RandomTasks(Tasks):
         return Task('', target)
 
 
+class Subtasks(Tasks):
+    """Staged task: a dialog and a sequence of structures; reset() samples one turn as the goal with the
+    previous structure as the starting grid (gridworld/tasks/task.py:208-308).  As in the reference the
+    created Task is invariant with the full structure as `full_grid` (the `invariant` argument is stored
+    but not forwarded, task.py:278-283)."""
+
+    def __init__(self, dialog, structure_seq, invariant=False, progressive=True):
+        self.dialog = dialog
+        self.invariant = invariant
+        self.progressive = progressive
+        self.structure_seq = structure_seq
+        self.next = None
+        self.full = False
+        self.task_start = 0
+        self.task_goal = 0
+        self.full_structure = self.to_dense(self.structure_seq[-1])
+        self.current = self.reset()
+
+    def __getattr__(self, name):
+        if name == 'current':
+            raise AttributeError(name)
+        return getattr(self.current, name)
+
+    def reset(self):
+        if self.next is None:
+            if len(self.structure_seq) == 1:
+                turn = -1
+            else:
+                turn = int(np.random.choice(len(self.structure_seq))) - 1
+            turn_goal = turn + 1
+        else:
+            turn = self.next
+            turn_goal = self.next + 1
+        self.task_start = turn
+        self.task_goal = turn_goal
+        self.current = self.create_task(self.task_start, self.task_goal)
+        return self.current
+
+    def __len__(self):
+        return len(self.structure_seq)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self.create_task(i - 1, i)
+
+    def create_task(self, turn_start, turn_goal):
+        dialog = ''
+        for turn in self.dialog[:turn_goal + 1]:
+            if isinstance(turn, list):
+                turn = '\n'.join(turn)
+            dialog += '\n' + turn if len(dialog) > 0 else turn
+        initial_blocks = [] if turn_start == -1 else self.structure_seq[turn_start]
+        tid = min(turn_goal, len(self.structure_seq) - 1) if not self.full else -1
+        target_grid = self.structure_seq[tid]
+        last = self.dialog[tid]
+        task = Task(dialog, target_grid=self.to_dense(target_grid),
+                    starting_grid=self.to_sparse(np.asarray(self.to_dense(initial_blocks))),
+                    full_grid=self.full_structure, last_instruction='\n'.join(last) if isinstance(last, list) else last)
+        task.reset()
+        return task
+
+
 def dummy_task():
     """DUMMY_TASK (task_set.py:160): one blue block at sparse (5, 7, 5); starting grid None == []."""
     return CustomTasks(goals=[('', [(5, 7, 5, 1)])], task_kwargs={'invariant': False})
