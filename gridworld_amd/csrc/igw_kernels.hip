@@ -294,17 +294,15 @@ template <int GS>
 struct BlockShared {
     static constexpr int EPB = BLOCK / GS;  // envs per block
     static constexpr int EPW = WAVE / GS;   // envs per wave
-    double lut[IGW_LUT_N * 2];
     uint32_t occ[EPB * OCC_PITCH];  // occupancy bitmaps, one per env
     WaveScratch ws[WAVES_PER_BLOCK];
 };
 
 __constant__ double IGW_TRIG_LUT_DEV[IGW_LUT_N * 2];
 
-__device__ inline void load_lut(double* lut_s) {
-    for (int i = threadIdx.x; i < IGW_LUT_N * 2; i += BLOCK) lut_s[i] = IGW_TRIG_LUT_DEV[i];
-    __syncthreads();
-}
+// The 2 KB table is read straight from constant memory (L2-resident, shared by every block); staging it in
+// LDS cost a block-wide barrier on every launch's critical path for a handful of lookups per step.
+__device__ inline const double* trig_lut() { return IGW_TRIG_LUT_DEV; }
 
 // the wave's EPW contiguous bitmap rows HBM -> LDS, coalesced dwordx4, LDS pitch OCC_PITCH
 template <int GS>
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     __shared__ BlockShared<GS> sh;
     const Grp<GS> G;
     TrigCtx trig;
-    trig.lut = sh.lut;
+    trig.lut = trig_lut();
     const int wave = threadIdx.x / WAVE;
     const int slot = threadIdx.x / GS;
     const int env = blockIdx.x * BlockShared<GS>::EPB + slot;
@@ -476,9 +474,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     const bool active = env < p.n_envs;
     uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
-    if (wave_env0 < p.n_envs) load_occ_wave<GS>(p, wave_env0, occ_wave_s);
-    load_lut(sh.lut);
     if (wave_env0 >= p.n_envs) return;
+    load_occ_wave<GS>(p, wave_env0, occ_wave_s);
     Env e = {};
     CellChange ch;
     ch.idx = -1; ch.old_val = ch.new_val = 0;
@@ -572,7 +569,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
     __shared__ BlockShared<GS> sh;
     const Grp<GS> G;
     TrigCtx trig;
-    trig.lut = sh.lut;
+    trig.lut = trig_lut();
     const int wave = threadIdx.x / WAVE;
     const int slot = threadIdx.x / GS;
     const int env = blockIdx.x * BlockShared<GS>::EPB + slot;
@@ -580,9 +577,8 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
     const bool active = env < p.n_envs;
     uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
-    if (wave_env0 < p.n_envs) load_occ_wave<GS>(p, wave_env0, occ_wave_s);
-    load_lut(sh.lut);
     if (wave_env0 >= p.n_envs) return;
+    load_occ_wave<GS>(p, wave_env0, occ_wave_s);
     Env e = {};
     int task = 0, env_max_int = 0;
     bool has_start = false;

@@ -1,0 +1,129 @@
+"""BASELINE full size (65,536 parallel envs, configs[2]/[3]) through size-independent properties:
+  * invariants that tie the outputs together (bitmap == grid != 0, inventory == 20 - colour counts,
+    prev_size == block count, persistent histogram == recount, max_int bounds);
+  * shard independence: every env computed inside the 65,536 batch equals the same env computed in a
+    4,096-env shard (so sharding over GPUs cannot change results);
+  * a random sample of the batch replayed through the CPU oracle (bit-exact);
+  * determinism (two runs -> identical bytes) and fused rollout == step-by-step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N = 65536
+
+
+def _run(n, T, seed, env_offset=0, task_seed=0, task_slice=None, mode='walking', rollout=False):
+    from gridworld_amd import VecGridWorld, workloads
+    env = VecGridWorld(n, size_reward=False, autoreset=True, max_steps=100, action_space=mode)
+    tg = workloads.rt20(N, seed=task_seed)
+    if task_slice is not None:
+        tg = tg[task_slice]
+    env.set_tasks(tg.to(env.device))
+    env.reset()
+    if rollout:
+        env.rollout(T, seed=seed, env_offset=env_offset)
+    else:
+        acts = env.fill_actions(T, seed=seed, env_offset=env_offset)
+        for t in range(T):
+            env.step_walking_ptr(acts[t])
+    torch.cuda.synchronize()
+    return env, tg
+
+
+def test_invariants_at_full_size():
+    from test_gpu_parity import _check_occ, _check_hist
+    T = 230  # two auto-resets (max_steps=100) plus a partial episode
+    env, tg = _run(N, T, seed=321)
+    st = env.stats()
+    assert st['resets'] >= 2 * N
+    grid = env.grid.cpu().numpy().reshape(N, -1)
+    inv = env.inventory.cpu().numpy()
+    ts = env.task_state()
+    _check_occ(env)
+    # inventory conservation: no starting grid -> inventory[c] == 20 - #cells of colour c+1
+    counts = np.stack([(grid == c + 1).sum(1) for c in range(6)], axis=1)
+    assert np.array_equal(inv, (20 - counts).astype(np.float32))
+    assert np.array_equal(ts['prev_size'], (grid != 0).sum(1))
+    tsize = (tg.numpy().reshape(N, -1) != 0).sum(1)
+    assert (ts['max_int'] <= np.minimum(tsize, ts['prev_size'])).all() and (ts['max_int'] >= 0).all()
+    assert (ts['step_no'] == T - 200).all() or st['resets'] > 2 * N   # completed targets reset earlier
+    assert ts['dirty'].sum() == 0                                      # impossible without a starting grid
+    _check_hist(env, tg.numpy(), sample=range(0, N, 997))
+    # checksum of checksums, stable across runs of the same seed (determinism)
+    env2, _ = _run(N, T, seed=321)
+    for a, b in ((env.grid_buf, env2.grid_buf), (env.agent_buf, env2.agent_buf), (env.hist_buf, env2.hist_buf),
+                 (env.occ_buf, env2.occ_buf), (env.reward, env2.reward), (env.agent_pos, env2.agent_pos)):
+        assert torch.equal(a, b)
+
+
+def test_shard_independence_and_oracle_sample():
+    from oracle import oracle as O
+    T = 150
+    full, tg = _run(N, T, seed=77)
+    fg, fa = full.grid_buf.cpu(), full.agent_buf.cpu()
+    # (a) 4,096-env shards with rank-style offsets reproduce their slice of the big batch
+    for lo in (0, 20480, 61440):
+        part, _ = _run(4096, T, seed=77, env_offset=lo, task_slice=slice(lo, lo + 4096))
+        assert torch.equal(part.grid_buf.cpu(), fg[lo:lo + 4096])
+        assert torch.equal(part.agent_buf.cpu(), fa[lo:lo + 4096])
+    # (b) 256 envs sampled across the batch, replayed on the CPU oracle with the same counter-RNG actions
+    idx = np.random.RandomState(3).choice(N, 256, replace=False)
+    acts = full.fill_actions(T, seed=77).cpu().numpy()[:, idx]
+    ob = O.OracleBatch(len(idx), size_reward=False, max_steps=100)
+    ob.set_tasks(tg.numpy()[idx])
+    ob.reset()
+    for t in range(T):
+        ob.step_walking(acts[t], autoreset=True, nthreads=8)
+    assert np.array_equal(full.grid.cpu().numpy().reshape(N, -1)[idx], ob.grid)
+    assert np.array_equal(full.internals()[idx].view(np.uint64), ob.internals().view(np.uint64))
+    assert np.array_equal(full.reward.cpu().numpy()[idx], ob.reward)
+    assert np.array_equal(full.agent_pos.cpu().numpy()[idx].view(np.uint32), ob.agentPos.view(np.uint32))
+
+
+def test_fused_rollout_equals_stepwise_at_full_size():
+    T = 120
+    a, _ = _run(N, T, seed=9)
+    b, _ = _run(N, T, seed=9, rollout=True)
+    assert torch.equal(a.grid_buf, b.grid_buf) and torch.equal(a.agent_buf, b.agent_buf)
+    assert torch.equal(a.hist_buf, b.hist_buf) and torch.equal(a.occ_buf, b.occ_buf)
+    assert a.stats()['changed'] == b.stats()['changed'] and a.stats()['resets'] == b.stats()['resets']
+
+
+def test_flying_full_size_invariants():
+    """configs[3]: 65,536 flying envs -- invariants plus an oracle sample in device-trig mode."""
+    from gridworld_amd import VecGridWorld, workloads
+    from oracle import oracle as O
+    from test_gpu_parity import _check_occ
+    T = 60
+    env = VecGridWorld(N, size_reward=False, autoreset=True, max_steps=50, action_space='flying')
+    tg = workloads.rt20(N, seed=4)
+    env.set_tasks(tg.to(env.device))
+    env.reset()
+    g = torch.Generator(device=env.device)
+    g.manual_seed(5)
+    mv = torch.rand((T, N, 3), generator=g, device=env.device) * 2 - 1
+    cam = torch.rand((T, N, 2), generator=g, device=env.device) * 10 - 5
+    inv = torch.randint(0, 7, (T, N), generator=g, device=env.device, dtype=torch.int32)
+    plc = torch.randint(0, 3, (T, N), generator=g, device=env.device, dtype=torch.int32)
+    idx = np.random.RandomState(8).choice(N, 128, replace=False)
+    O.use_device_trig(True)
+    try:
+        ob = O.OracleBatch(len(idx), size_reward=False, max_steps=50, action_space='flying')
+        ob.set_tasks(tg.numpy()[idx])
+        ob.reset()
+        for t in range(T):
+            env.step(dict(movement=mv[t], camera=cam[t], inventory=inv[t], placement=plc[t]))
+            ob.step_flying(mv[t].cpu().numpy()[idx], cam[t].cpu().numpy()[idx], inv[t].cpu().numpy()[idx],
+                           plc[t].cpu().numpy()[idx], autoreset=True, nthreads=8)
+        torch.cuda.synchronize()
+        assert np.array_equal(env.grid.cpu().numpy().reshape(N, -1)[idx], ob.grid)
+        assert np.array_equal(env.internals()[idx].view(np.uint64), ob.internals().view(np.uint64))
+    finally:
+        O.use_device_trig(False)
+    _check_occ(env)
+    grid = env.grid.cpu().numpy().reshape(N, -1)
+    counts = np.stack([(grid == c + 1).sum(1) for c in range(6)], axis=1)
+    assert np.array_equal(env.inventory.cpu().numpy(), (20 - counts).astype(np.float32))
+    assert np.array_equal(env.task_state()['prev_size'], (grid != 0).sum(1))
