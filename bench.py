@@ -36,41 +36,38 @@ BYTES_BASE, BYTES_CHANGED = 1274, 1106
 
 
 def cpu_baseline(seed):
-    """Oracle (port of the reference algorithm) on the host: all cores, bounded sample."""
-    import numpy as np
+    """Oracle (plain-C port of the reference algorithm) on the host cores: a bounded sample of the same
+    workload (rt20 targets, counter-RNG uniform actions, resets included), sized for ~10 s of wall time."""
     from gridworld_amd import workloads
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0))
     kw = dict(size_reward=False)
-    # calibrate on a small batch, then size the sample for ~10 s of wall time
-    n0, T = 64 * min(cores, 16), 250
-    tg = workloads.rt20(n0, seed).numpy()
-    b = O.OracleBatch(n0, **kw)
-    b.set_tasks(tg)
-    b.reset()
-    t = time.perf_counter()
-    b.rollout_walking(25, seed, autoreset=True, nthreads=cores)
-    rate0 = n0 * 25 / (time.perf_counter() - t)
-    n = int(min(65536, max(n0, (rate0 * 12 / T) // 64 * 64)))  # ~12 s of all-core work
+    n = int(min(16384, max(256, 64 * cores)))
     tg = workloads.rt20(n, seed).numpy()
     b = O.OracleBatch(n, **kw)
     b.set_tasks(tg)
     b.reset()
     t = time.perf_counter()
+    b.rollout_walking(10, seed, autoreset=True, nthreads=cores)  # calibration (also warms the threads)
+    rate0 = n * 10 / (time.perf_counter() - t)
+    T = int(min(1500, max(250, round(rate0 * 8 / n / 250) * 250)))
+    b.reset()
+    t = time.perf_counter()
     steps, changed = b.rollout_walking(T, seed, autoreset=True, nthreads=cores)
     dt = time.perf_counter() - t
     # one core, smaller sample
-    n1 = max(64, n // max(cores, 1) // 64 * 64)
+    n1 = max(256, min(1024, n // 8))
     b1 = O.OracleBatch(n1, **kw)
     b1.set_tasks(tg[:n1])
     b1.reset()
     t = time.perf_counter()
-    s1, _ = b1.rollout_walking(T, seed, autoreset=True, nthreads=1)
+    s1, _ = b1.rollout_walking(250, seed, autoreset=True, nthreads=1)
     dt1 = time.perf_counter() - t
     return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} envs x {T} steps, rt20 targets, counter-RNG uniform actions, resets included '
                       f'({dt:.1f} s on {cores} threads)',
-            'value_1core': s1 / dt1, 'p_changed': changed / max(steps, 1)}
+            'value_1core': s1 / dt1, 'sample_1core': f'{n1} envs x 250 steps ({dt1:.1f} s)',
+            'p_changed': changed / max(steps, 1)}
 
 
 def load_traffic():

@@ -21,7 +21,7 @@ WALKING_DISCRETE, FLYING, WALKING_DICT = 0, 1, 2
 RESET_KEEP_SIZE = 1
 
 # every symbol include/igw.h declares (checked by tests/test_abi.py)
-EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy',
+EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',
            'igw_bind_buffers', 'igw_prepare_tasks', 'igw_reset', 'igw_step_walking', 'igw_step_flying',
            'igw_step_walking_dict',
            'igw_rollout_walking', 'igw_fill_actions_walking', 'igw_task_eval']
@@ -69,6 +69,7 @@ def load(build_if_missing=True):
     L.igw_device_count.restype = C.c_int
     L.igw_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.igw_destroy.argtypes = [vp]
+    L.igw_debug_set_stamps.argtypes = [vp, vp]
     L.igw_bind_buffers.argtypes = [vp, C.POINTER(Buffers)]
     L.igw_prepare_tasks.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.igw_reset.argtypes = [vp, vp, i32, vp]

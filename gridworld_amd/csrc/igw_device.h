@@ -88,6 +88,7 @@ struct KParams {
     float* reward;
     uint8_t* done;
     unsigned long long* stats;
+    unsigned long long* stamps;  // diagnostic builds only: [waves][8] s_memtime stamps (igw_debug_set_stamps)
 };
 
 // ---------------------------------------------------------------- lane groups
@@ -196,11 +197,11 @@ __device__ inline void env_store(const Env& e, AgentRec* rec) {
 
 // core/world.py:57-58
 __device__ inline bool build_zone_d(double x, double y, double z, double pad) {
-    return -5.0 - pad <= x && x <= 5.0 + pad && -5.0 - pad <= z && z <= 5.0 + pad && -1.0 - pad <= y &&
-           y < 8.0 + pad;
+    // -5-pad <= x <= 5+pad  <=>  |x| <= 5+pad (exact); likewise z
+    return __builtin_fabs(x) <= 5.0 + pad && __builtin_fabs(z) <= 5.0 + pad && -1.0 - pad <= y && y < 8.0 + pad;
 }
 __device__ inline bool build_zone_i(int x, int y, int z) {
-    return x >= -5 && x <= 5 && z >= -5 && z <= 5 && y >= -1 && y < 8;
+    return (unsigned)(x + 5) <= 10u && (unsigned)(z + 5) <= 10u && (unsigned)(y + 1) <= 8u;
 }
 __device__ inline int cell_of(int x, int y, int z) { return (y + 1) * LEVEL + (x + 5) * 11 + (z + 5); }
 
@@ -251,40 +252,56 @@ __device__ inline double div5(double x) {
 
 // ---------------------------------------------------------------- collide (core/world.py:264-310)
 
+// Neighbourhood prober for collide: the 12 probes are np + small offsets, so the range checks of
+// world_has (build zone per axis, ground plane y == -2 inside |x|,|z| <= 18) are hoisted per axis value
+// and a probe is one add + one LDS bit test.
+struct Probe {
+    const uint32_t* occ_s;
+    int base;            // cell_of(nx, ny, nz), may be out of range; only used when the axes are valid
+    int nx, ny, nz;
+    __device__ bool at(int dx, int dy, int dz) const {
+        const int x = nx + dx, y = ny + dy, z = nz + dz;
+        if (y == -2) return x >= -18 && x <= 18 && z >= -18 && z <= 18;
+        const bool in = (unsigned)(x + 5) <= 10u && (unsigned)(z + 5) <= 10u && (unsigned)(y + 1) <= 8u;
+        return in && occ_test(occ_s, base + dy * LEVEL + dx * 11 + dz);
+    }
+};
+
 // Six faces in the reference order; a face only probes when its overlap test passes.  (Issuing all 12
 // probes up front -- they depend only on np -- was measured slower at every group size.)
 __device__ inline void collide(Env& e, const uint32_t* occ_s, double& px, double& py, double& pz) {
     const int nx = (int)__builtin_rint(px), ny = (int)__builtin_rint(py), nz = (int)__builtin_rint(pz);
+    const Probe w{occ_s, cell_of(nx, ny, nz), nx, ny, nz};
     double d;
-    d = (py - (double)ny) * 1.0;  // face (0, 1, 0)
+    d = (py - (double)ny) * 1.0;  // face (0, 1, 0): heights dy = 0, 1 probe (nx, ny - dy + 1, nz)
     if (!(d < PAD)) {
-        if (world_has(occ_s, nx, ny + 1, nz) || world_has(occ_s, nx, ny, nz)) {
+        if (w.at(0, 1, 0) || w.at(0, 0, 0)) {
             py -= (d - PAD) * 1.0;
             e.vy = 0.0;
         }
     }
     d = (py - (double)ny) * -1.0;  // face (0, -1, 0)
     if (!(d < PAD)) {
-        if (world_has(occ_s, nx, ny - 1, nz) || world_has(occ_s, nx, ny - 2, nz)) {
+        if (w.at(0, -1, 0) || w.at(0, -2, 0)) {
             py -= (d - PAD) * -1.0;
             e.vy = 0.0;
         }
     }
     d = (px - (double)nx) * -1.0;  // face (-1, 0, 0)
     if (!(d < PAD)) {
-        if (world_has(occ_s, nx - 1, ny, nz) || world_has(occ_s, nx - 1, ny - 1, nz)) px -= (d - PAD) * -1.0;
+        if (w.at(-1, 0, 0) || w.at(-1, -1, 0)) px -= (d - PAD) * -1.0;
     }
     d = (px - (double)nx) * 1.0;  // face (1, 0, 0)
     if (!(d < PAD)) {
-        if (world_has(occ_s, nx + 1, ny, nz) || world_has(occ_s, nx + 1, ny - 1, nz)) px -= (d - PAD) * 1.0;
+        if (w.at(1, 0, 0) || w.at(1, -1, 0)) px -= (d - PAD) * 1.0;
     }
     d = (pz - (double)nz) * 1.0;  // face (0, 0, 1)
     if (!(d < PAD)) {
-        if (world_has(occ_s, nx, ny, nz + 1) || world_has(occ_s, nx, ny - 1, nz + 1)) pz -= (d - PAD) * 1.0;
+        if (w.at(0, 0, 1) || w.at(0, -1, 1)) pz -= (d - PAD) * 1.0;
     }
     d = (pz - (double)nz) * -1.0;  // face (0, 0, -1)
     if (!(d < PAD)) {
-        if (world_has(occ_s, nx, ny, nz - 1) || world_has(occ_s, nx, ny - 1, nz - 1)) pz -= (d - PAD) * -1.0;
+        if (w.at(0, 0, -1) || w.at(0, -1, -1)) pz -= (d - PAD) * -1.0;
     }
 }
 

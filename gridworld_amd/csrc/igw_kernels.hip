@@ -37,6 +37,16 @@ struct StepOut {
     bool done;
 };
 
+// In-kernel phase stamps (diagnostic only, never in a timed run): drain this wave's memory queues so the
+// time is charged to the phase that caused the wait, then read the shader clock.
+__device__ inline void stamp(const KParams& p, int slot) {
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (__lane_id() == 0) p.stamps[((size_t)blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE) * 8 + slot] = t;
+    }
+}
+
 __device__ inline void stat_add(unsigned long long* stats, int which, unsigned long long v) {
     if (stats) atomicAdd(&stats[(blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + which], v);
 }
@@ -166,6 +176,7 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
             wave_sync();
         }
     }
+    stamp(p, 2);
     // update(dt = 1/20), :203-220
     {
         const int m = e.tis;
@@ -218,6 +229,7 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
         }
         if (FLY) e.vy = 0.0;
     }
+    stamp(p, 3);
     // yaw wrap with strict comparisons (0 and 360 both survive), :451-456
     while (e.yaw > 360.0) e.yaw -= 360.0;
     while (e.yaw < 0.0) e.yaw += 360.0;
@@ -475,6 +487,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
     if (wave_env0 >= p.n_envs) return;
+    stamp(p, 0);
     load_occ_wave<GS>(p, wave_env0, occ_wave_s);
     Env e = {};
     CellChange ch;
@@ -487,6 +500,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
         task = p.env_task[env];  // prefetched: only consumed if the grid changes or the episode ends
         env_load(e, p.agent + env);
         wave_sync();
+        stamp(p, 1);
         e.step_no = min(e.step_no + 1, 65535);  // env.py:276
         if (MODE == MODE_WALK) {
             ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, a.actions[env]);
@@ -511,6 +525,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
         if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
         if (p.size_reward && e.step_no == 1) env_max_int = p.task_meta[task].env_max_int;
     }
+    stamp(p, 4);
     int incmax = 0;
     bool decd = false;
     const bool changed = active && ch.idx >= 0 && !(p.debug & 1);
@@ -531,6 +546,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
             e.dirty = 1;  // the reference keeps its cached max_int here although the grid changed
         }
     }
+    stamp(p, 5);
     mi = resolve_rescans<GS>(G, p, rescan, env, mi);
     StepOut o;
     o.reward = 0.0; o.done = false;
@@ -560,6 +576,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
         if (rescan) stat_add(p.stats, IGW_STAT_RESCANS, 1);
         if (do_reset) stat_add(p.stats, IGW_STAT_RESETS, 1);
     }
+    stamp(p, 6);
 }
 
 // T fused walking steps, state resident in registers + LDS, counter-RNG actions, auto-reset on done
@@ -960,6 +977,12 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
         if (e != hipSuccess) { delete c; return fail(IGW_ERR_HIP, "igw_create: LUT upload: %s", hipGetErrorString(e)); }
     }
     *out = c;
+    return IGW_OK;
+}
+
+int igw_debug_set_stamps(igw_ctx* ctx, uint64_t* stamps) {
+    if (!ctx) return fail(IGW_ERR_INVALID, "igw_debug_set_stamps: null context");
+    ctx->kp.stamps = reinterpret_cast<unsigned long long*>(stamps);
     return IGW_OK;
 }
 

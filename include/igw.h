@@ -151,6 +151,9 @@ int igw_device_count(void);
 
 int igw_create(const igw_config* cfg, igw_ctx** out);
 int igw_destroy(igw_ctx* ctx);
+/* diagnostic: device uint64 [waves][8] receiving in-kernel s_memtime phase stamps of the step kernels
+ * (drains the wave's memory queues at every stamp, so never set it in a timed run); NULL disables */
+int igw_debug_set_stamps(igw_ctx* ctx, uint64_t* stamps);
 int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* bufs);
 
 /* Fills task-table rows [first, first+n): user_target / start / full_grid are device
