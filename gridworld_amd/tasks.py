@@ -174,21 +174,25 @@ class Subtasks(Tasks):
         for i in range(len(self)):
             yield self.create_task(i - 1, i)
 
+    def _dialog_until(self, last_turn):
+        """Utterances 0..last_turn joined by newlines; a multi-line turn is flattened first and an empty
+        running text takes the next turn without a separator (task.py:266-270)."""
+        text = ''
+        for turn in self.dialog[:last_turn + 1]:
+            line = '\n'.join(turn) if isinstance(turn, list) else turn
+            text = line if not text else text + '\n' + line
+        return text
+
     def create_task(self, turn_start, turn_goal):
-        dialog = ''
-        for turn in self.dialog[:turn_goal + 1]:
-            if isinstance(turn, list):
-                turn = '\n'.join(turn)
-            dialog += '\n' + turn if len(dialog) > 0 else turn
-        initial_blocks = [] if turn_start == -1 else self.structure_seq[turn_start]
-        tid = min(turn_goal, len(self.structure_seq) - 1) if not self.full else -1
-        target_grid = self.structure_seq[tid]
-        last = self.dialog[tid]
-        task = Task(dialog, target_grid=self.to_dense(target_grid),
-                    starting_grid=self.to_sparse(np.asarray(self.to_dense(initial_blocks))),
-                    full_grid=self.full_structure, last_instruction='\n'.join(last) if isinstance(last, list) else last)
-        task.reset()
-        return task
+        goal_idx = -1 if self.full else min(turn_goal, len(self.structure_seq) - 1)
+        start_blocks = self.structure_seq[turn_start] if turn_start >= 0 else []
+        instruction = self.dialog[goal_idx]
+        task = Task(self._dialog_until(turn_goal),
+                    target_grid=self.to_dense(self.structure_seq[goal_idx]),
+                    starting_grid=self.to_sparse(np.asarray(self.to_dense(start_blocks))),
+                    full_grid=self.full_structure,
+                    last_instruction='\n'.join(instruction) if isinstance(instruction, list) else instruction)
+        return task.reset()
 
 
 def dummy_task():
