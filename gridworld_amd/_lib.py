@@ -22,7 +22,7 @@ RESET_KEEP_SIZE = 1
 
 # every symbol include/igw.h declares (checked by tests/test_abi.py)
 EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',
-           'igw_bind_buffers', 'igw_prepare_tasks', 'igw_reset', 'igw_step_walking', 'igw_step_flying',
+           'igw_bind_buffers', 'igw_prepare_tasks', 'igw_set_task_sampling', 'igw_reset', 'igw_step_walking', 'igw_step_flying',
            'igw_step_walking_dict',
            'igw_rollout_walking', 'igw_fill_actions_walking', 'igw_task_eval']
 
@@ -73,6 +73,7 @@ def load(build_if_missing=True):
     L.igw_bind_buffers.argtypes = [vp, C.POINTER(Buffers)]
     L.igw_prepare_tasks.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.igw_reset.argtypes = [vp, vp, i32, vp]
+    L.igw_set_task_sampling.argtypes = [vp, i32, u64]
     L.igw_step_walking.argtypes = [vp, vp, vp]
     L.igw_step_flying.argtypes = [vp, vp, vp, vp, vp, vp]
     L.igw_step_walking_dict.argtypes = [vp, vp, vp, vp]

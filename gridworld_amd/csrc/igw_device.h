@@ -72,12 +72,15 @@ static_assert(sizeof(TaskMeta) == IGW_TASK_META_BYTES, "task meta layout");
 struct KParams {
     int32_t n_envs, select_and_place, size_reward, max_steps, autoreset;
     int32_t debug;  // timing-only ablation switches (igw_config.reserved); 0 in every parity / bench run
+    int32_t sample_tasks, n_tasks;  // igw_set_task_sampling: draw env_task uniformly from the table at every reset
+    unsigned long long sample_seed;
+    long long tick;                 // launches so far (keys the sampler)
     double right_scale, wrong_scale;
     int8_t* grid;
     uint32_t* occ;
     uint16_t* hist;
     AgentRec* agent;
-    const int32_t* env_task;
+    int32_t* env_task;
     const int8_t* task_target;
     const int8_t* task_start;
     const uint32_t* task_start_occ;
@@ -148,6 +151,11 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
+}
+// uniform task index in [0, n): CustomTasks.reset() (gridworld/tasks/task_set.py:53-56) on the device
+__host__ __device__ inline int rng_task(uint64_t seed, uint64_t env, uint64_t tick, int n) {
+    uint64_t h = splitmix64(seed ^ splitmix64(env * 0x9E3779B1ull + tick * 0x100000001B3ull + 0x7461736bull));
+    return (int)(((h >> 32) * (uint64_t)n) >> 32);
 }
 __host__ __device__ inline int rng_action18(uint64_t seed, uint64_t env, uint64_t t) {
     uint64_t h = splitmix64(seed ^ splitmix64(env * 0x100000001B3ull + t));

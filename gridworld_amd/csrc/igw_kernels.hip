@@ -555,6 +555,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
         o = finish_step(p, e, env_max_int, size_new, mi);
         do_reset = o.done && p.autoreset;
         if (do_reset) {
+            if (p.sample_tasks) {  // the next episode's task (task generator on the device)
+                task = rng_task(p.sample_seed, (uint64_t)env, (uint64_t)p.tick, p.n_tasks);
+                if (G.gl == 0) p.env_task[env] = task;
+            }
             meta = p.task_meta + task;
             has_start = meta->has_start != 0;
         }
@@ -653,6 +657,13 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
             // colours go to HBM right away (a later break of this launch reads them)
             if (ch.idx >= 0 && !do_reset && G.gl == 0) grid_g[ch.idx] = (int8_t)ch.new_val;
         }
+        if (active && do_reset && p.sample_tasks) {
+            task = rng_task(p.sample_seed, (uint64_t)env, (uint64_t)(p.tick + t), p.n_tasks);
+            if (G.gl == 0) p.env_task[env] = task;
+            meta = p.task_meta + task;
+            has_start = meta->has_start != 0;
+            env_max_int = meta->env_max_int;
+        }
         wave_sync();
         resolve_resets<GS>(G, p, do_reset, env, task, has_start, occ_wave_s);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -685,7 +696,11 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(KParams p, const uint8_t* 
     if (mask && !mask[env]) return;
     Env e;
     env_load(e, p.agent + env);
-    const int task = p.env_task[env];
+    int task = p.env_task[env];
+    if (p.sample_tasks) {
+        task = rng_task(p.sample_seed, (uint64_t)env, (uint64_t)p.tick, p.n_tasks);
+        if (__lane_id() == 0) p.env_task[env] = task;
+    }
     const TaskMeta* meta = p.task_meta + task;
     reset_rows_wave(p, env, task, meta->has_start != 0, nullptr);
     reset_env_regs(e, meta, keep_size != 0);
@@ -980,6 +995,14 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     return IGW_OK;
 }
 
+int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed) {
+    if (!ctx) return fail(IGW_ERR_INVALID, "igw_set_task_sampling: null context");
+    ctx->kp.sample_tasks = enabled ? 1 : 0;
+    ctx->kp.n_tasks = ctx->cfg.num_tasks;
+    ctx->kp.sample_seed = seed;
+    return IGW_OK;
+}
+
 int igw_debug_set_stamps(igw_ctx* ctx, uint64_t* stamps) {
     if (!ctx) return fail(IGW_ERR_INVALID, "igw_debug_set_stamps: null context");
     ctx->kp.stamps = reinterpret_cast<unsigned long long*>(stamps);
@@ -1060,6 +1083,7 @@ int igw_reset(igw_ctx* ctx, const uint8_t* mask, int32_t flags, void* stream) {
     const int keep = (flags & IGW_RESET_KEEP_SIZE) ? 1 : 0;
     const int blocks = (ctx->cfg.num_envs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, ctx->kp, mask, keep);
+    ctx->kp.tick += 1;
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1071,6 +1095,7 @@ int igw_step_walking(igw_ctx* ctx, const int32_t* actions, void* stream) {
     ActIn a = {actions, nullptr, nullptr, nullptr, nullptr, nullptr};
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_WALK>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, a));
+    ctx->kp.tick += 1;
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1083,6 +1108,7 @@ int igw_step_flying(igw_ctx* ctx, const float* movement, const float* camera, co
     ActIn a = {nullptr, movement, camera, inventory, placement, nullptr};
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_FLY>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, a));
+    ctx->kp.tick += 1;
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1095,6 +1121,7 @@ int igw_step_walking_dict(igw_ctx* ctx, const uint8_t* buttons, const float* cam
     ActIn a = {nullptr, nullptr, camera, nullptr, nullptr, buttons};
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_WALK_DICT>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, a));
+    ctx->kp.tick += 1;
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1107,6 +1134,7 @@ int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int6
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(rollout_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, (long long)T, (unsigned long long)seed,
                                             (long long)t0, (long long)env_offset));
+    ctx->kp.tick += T;
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }

@@ -125,6 +125,22 @@ class VecGridWorld:
         self._keep = (tgt, st, fg, inv, pose)  # keep inputs alive until the async kernel ran
         self._have_tasks = True
 
+    def set_task_sampling(self, enabled=True, seed=0):
+        """Draw every env's task uniformly from the task table at each reset / auto-reset, on the device
+        (CustomTasks.reset semantics; counter RNG keyed by seed, env and the number of launches so far)."""
+        L.check(self.lib.igw_set_task_sampling(self.ctx, int(bool(enabled)), int(seed)), 'igw_set_task_sampling')
+
+    def state_dict(self):
+        """Snapshot of the complete env state (tensors are cloned): resume / parity debugging."""
+        keys = ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'env_task', 'task_target', 'task_start',
+                'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass', 'reward', 'done', 'stats_buf')
+        return {k: getattr(self, k).clone() for k in keys}
+
+    def load_state_dict(self, state):
+        for k, v in state.items():
+            getattr(self, k).copy_(v)
+        self._have_tasks = True
+
     # ---- reset / step ----
     def _need_tasks(self):
         if not self._have_tasks:

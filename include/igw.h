@@ -163,6 +163,12 @@ int igw_prepare_tasks(igw_ctx* ctx, int32_t first, int32_t n, const int8_t* user
                       const int8_t* start, const int8_t* full_grid, const uint8_t* invariant,
                       const double* init_pose, void* stream);
 
+/* Task generator on the device (CustomTasks.reset, gridworld/tasks/task_set.py:53-56): when enabled every
+ * reset -- igw_reset and the auto-reset inside the step kernels -- first draws env_task uniformly from the
+ * task table with a counter RNG keyed by (seed, env, number of launches so far).  Same distribution as the
+ * reference's np.random.choice, not the same stream. */
+int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed);
+
 #define IGW_RESET_KEEP_SIZE 1 /* GridWorld.reset only (what set_task calls): SizeReward.size survives */
 /* mask: device uint8[N] or NULL (= all envs) */
 int igw_reset(igw_ctx* ctx, const uint8_t* mask, int32_t flags, void* stream);

@@ -1,0 +1,102 @@
+"""Device-side task sampling at reset (CustomTasks.reset semantics) and state snapshots."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_task_sampling_on_autoreset_matches_oracle():
+    from gridworld_amd import VecGridWorld, workloads
+    from oracle import oracle as O
+    n, T, ntasks = 1500, 130, 37
+    kw = dict(size_reward=False, max_steps=30)
+    tg = workloads.rt20(ntasks, seed=31).numpy()
+    st = np.zeros_like(tg)
+    st[::3, 0, 5, 5] = 2   # a third of the tasks come with a starting block
+    env = VecGridWorld(n, num_tasks=ntasks, autoreset=True, **kw)
+    env.set_tasks(tg, st, env_task=np.zeros(n, np.int32))
+    env.set_task_sampling(True, seed=99)
+    env.reset()
+    torch.cuda.synchronize()
+    cur = env.env_task.cpu().numpy().copy()
+    assert cur.min() >= 0 and cur.max() < ntasks and len(np.unique(cur)) == ntasks
+    envs = [O.OracleEnv(**kw) for _ in range(n)]
+    for e, o in enumerate(envs):
+        o.set_task(tg[cur[e]], st[cur[e]])
+        o.reset()
+    acts = env.fill_actions(T, seed=5).cpu().numpy()
+    seen = [cur.copy()]
+    for t in range(T):
+        env.step(torch.as_tensor(acts[t]))
+        torch.cuda.synchronize()
+        done = env.done.cpu().numpy().astype(bool)
+        new = env.env_task.cpu().numpy()
+        rew = env.reward.cpu().numpy()
+        for e, o in enumerate(envs):
+            _, r, d, _ = o.step(int(acts[t, e]))
+            assert d == done[e] and np.float32(r) == rew[e], (t, e)
+            if d:   # the device picked the next task; tell the oracle which one and reset it
+                o.set_task(tg[new[e]], st[new[e]])
+                o.reset()
+            else:
+                assert new[e] == cur[e]
+        cur = new.copy()
+        if done.any():
+            seen.append(new[done])
+    grid = env.grid.cpu().numpy().reshape(n, -1)
+    internals = env.internals()
+    for e, o in enumerate(envs):
+        assert np.array_equal(grid[e], o.obs()['grid'].reshape(-1).astype(np.int8)), e
+        assert np.array_equal(internals[e].view(np.uint64), o.internal().view(np.uint64)), e
+    picks = np.concatenate(seen)
+    counts = np.bincount(picks, minlength=ntasks)
+    assert counts.min() > 0.5 * counts.mean() and counts.max() < 1.5 * counts.mean()   # roughly uniform
+
+
+def test_sampling_is_deterministic_and_rollout_consistent():
+    from gridworld_amd import VecGridWorld, workloads
+    n, T, ntasks = 2048, 90, 11
+    tg = workloads.rt20(ntasks, seed=1)
+
+    def run(rollout):
+        env = VecGridWorld(n, num_tasks=ntasks, autoreset=True, size_reward=False, max_steps=25)
+        env.set_tasks(tg.to(env.device), env_task=np.zeros(n, np.int32))
+        env.set_task_sampling(True, seed=7)
+        env.reset()
+        if rollout:
+            env.rollout(T, seed=3)
+        else:
+            a = env.fill_actions(T, seed=3)
+            for t in range(T):
+                env.step_walking_ptr(a[t])
+        torch.cuda.synchronize()
+        return env
+    a, b, c = run(False), run(False), run(True)
+    for x, y in ((a, b), (a, c)):
+        assert torch.equal(x.env_task, y.env_task) and torch.equal(x.grid_buf, y.grid_buf)
+        assert torch.equal(x.agent_buf, y.agent_buf) and torch.equal(x.hist_buf, y.hist_buf)
+
+
+def test_state_dict_roundtrip():
+    from gridworld_amd import VecGridWorld, workloads
+    n = 512
+    env = VecGridWorld(n, autoreset=True, size_reward=False, max_steps=40)
+    env.set_tasks(workloads.rt20(n, seed=2).to(env.device))
+    env.reset()
+    acts = env.fill_actions(120, seed=8)
+    for t in range(60):
+        env.step_walking_ptr(acts[t])
+    snap = env.state_dict()
+    for t in range(60, 120):
+        env.step_walking_ptr(acts[t])
+    torch.cuda.synchronize()
+    final = env.state_dict()
+    env2 = VecGridWorld(n, autoreset=True, size_reward=False, max_steps=40)
+    env2.load_state_dict(snap)
+    for t in range(60, 120):
+        env2.step_walking_ptr(acts[t])
+    torch.cuda.synchronize()
+    for k, v in final.items():
+        if k != 'stats_buf':
+            assert torch.equal(v, getattr(env2, k)), k
