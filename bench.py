@@ -174,7 +174,7 @@ def main():
 
     if rank != 0:
         return
-    lanes = env.cfg.lanes_per_env or 4
+    lanes = env.cfg.lanes_per_env or (2 if flying else 4)
     p = (st1['changed'] - st0['changed']) / float(N * K)
     resets = st1['resets'] - st0['resets']
     bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4

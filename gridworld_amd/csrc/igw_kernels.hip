@@ -131,10 +131,14 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
         y = -90.0 > y ? -90.0 : y;
         e.pitch = y;
     }
+    // sin / cos of the (post-camera) pitch feed both the sight vector and, when flying, the motion vector:
+    // evaluate once (same argument => same value as the reference's two calls)
+    double sp = 0.0, cp = 1.0;
+    const bool want_sight = add != remove && !(p.debug & 2);
+    if (want_sight || (FLY && (s0 != 0.0 || s1 != 0.0))) sincos_deg(trig, e.pitch, sp, cp);
     // place_or_remove_block, :312-332
-    if (add != remove && !(p.debug & 2)) {
-        double sp, cp, sy, cy;
-        sincos_deg(trig, e.pitch, sp, cp);       // m = cos(radians(y)); dy = sin(radians(y))
+    if (want_sight) {
+        double sy, cy;                           // m = cos(radians(y)); dy = sin(radians(y))
         sincos_deg(trig, e.yaw - 90.0, sy, cy);  // dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
         const double vx = cy * cp, vy = sp, vz = sy * cp;
         const Hit h = hit_test<GS>(G, occ_s, e.x, e.y, e.z, vx, vy, vz);
@@ -191,8 +195,6 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
             double sx, cx;
             sincos_deg(trig, e.yaw + strafe_deg, sx, cx);
             if (FLY) {
-                double sp, cp;
-                sincos_deg(trig, e.pitch, sp, cp);
                 double mm = cp;
                 mvy = sp;
                 if (s1 != 0.0) { mvy = 0.0; mm = 1.0; }
@@ -964,7 +966,8 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     if (cfg->action_space != IGW_WALKING_DISCRETE && cfg->action_space != IGW_FLYING &&
         cfg->action_space != IGW_WALKING_DICT)
         return fail(IGW_ERR_INVALID, "igw_create: unknown action_space");
-    int gs = cfg->lanes_per_env ? cfg->lanes_per_env : IGW_DEFAULT_LANES_PER_ENV;
+    int gs = cfg->lanes_per_env ? cfg->lanes_per_env
+                                : (cfg->action_space == IGW_FLYING ? IGW_DEFAULT_LANES_PER_ENV_FLYING : IGW_DEFAULT_LANES_PER_ENV);
     if (gs != 64 && gs != 32 && gs != 16 && gs != 8 && gs != 4 && gs != 2 && gs != 1)
         return fail(IGW_ERR_INVALID, "igw_create: lanes_per_env must be 0 or a power of two in 1..64");
     int n = 0;

@@ -38,6 +38,7 @@ extern "C" {
 /* lanes of a wavefront that cooperate on one env when igw_config.lanes_per_env == 0 (measured optimum
  * for per-step launches at 65,536 envs on MI355X; 64 = one wavefront per env) */
 #define IGW_DEFAULT_LANES_PER_ENV 4
+#define IGW_DEFAULT_LANES_PER_ENV_FLYING 2 /* heavier per-env arithmetic (general trig) favours narrower groups */
 
 /* dense voxel grid [y+1][x+5][z+5], int8 (env.py:34, 136-142) */
 #define IGW_GRID_Y 9
