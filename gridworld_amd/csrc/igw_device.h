@@ -1,11 +1,12 @@
 // igw_device.h -- device-side building blocks of the gridworld step path (gfx950, wave64).
 //
-// Execution model: GS lanes of a wavefront (GS = 64, 32, 16 or 8; "group") own one env.
+// Execution model: GS lanes of a wavefront (GS = 64, 32, ..., 1; a "group") own one env.
 // The serial double-precision physics chain is evaluated redundantly by every lane of the
-// group (no broadcast needed, the wave issues the instruction anyway); the lanes split
-//   * the coalesced int8 grid load/store HBM <-> LDS,
-//   * the 40 ray-march samples of hit_test,
-//   * the (target block, grid block) vote of maximal_intersection (whole wave, one env at a time).
+// group (no broadcast needed, the wave issues the instruction anyway); the lanes of a group
+// split the 40 ray-march samples of hit_test.  The per-step working set of an env is its
+// 144-byte occupancy bitmap, staged in LDS; the int8 colour grid stays in HBM and is touched
+// only where a colour matters.  Row-sized or rare work (histogram updates, rescans, resets,
+// Task.__init__) is done by the whole wave, coalesced.
 // All arithmetic is IEEE binary64 with one rounding per operation, in the reference's
 // operation order (compile with -ffp-contract=off, never fast-math).
 #pragma once
@@ -395,7 +396,10 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
     }
 }
 
-// ---------------------------------------------------------------- maximal_intersection
+// ---------------------------------------------------------------- maximal_intersection, full vote
+// Used where there is no running histogram: Task.__init__ (GridWorld.max_int of the user task on the
+// starting grid) and the stateless igw_task_eval.  The step kernels update a persistent histogram
+// incrementally instead (resolve_changes in igw_kernels.hip).
 // (tasks/task.py:147-161 restated as a vote: every (target block, grid block) pair on the same
 // level with equal non-zero value votes for translation (tx - gx, tz - gz) of each rotation; the
 // answer is the best admissible bin.  Admissible set == bounding-box rule, tasks/task.py:62-72.)
@@ -517,14 +521,4 @@ __device__ inline void row_to_lds_wave(int8_t* dst_s, const int8_t* src_g) {
     uint4* d = reinterpret_cast<uint4*>(dst_s);
     for (int c = lane; c < CHUNKS; c += WAVE) d[c] = s[c];
 }
-// same, bypassing this CU's vector L1 (agent-scope relaxed loads): used where the kernel itself wrote
-// bytes of the row earlier in the launch (fused rollout)
-__device__ inline void row_to_lds_wave_coherent(int8_t* dst_s, const int8_t* src_g) {
-    const int lane = __lane_id();
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(src_g);
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst_s);
-    for (int c = lane; c < STRIDE / 4; c += WAVE)
-        d[c] = __hip_atomic_load(s + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 }  // namespace igw
