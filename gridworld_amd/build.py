@@ -36,12 +36,24 @@ def is_stale():
 
 
 def build(force=False, extra_flags=(), verbose=False):
+    """Compiles under an exclusive file lock and installs the result with an atomic rename, so several
+    ranks starting at once (torchrun) never see or write a half-built library."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.run(cmd, check=True)
+    import fcntl
+    with open(LIB + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():  # another process built it while we waited
+                return LIB
+            tmp = f'{LIB}.tmp.{os.getpid()}'
+            cmd = [hipcc()] + FLAGS + list(extra_flags) + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

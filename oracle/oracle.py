@@ -36,15 +36,21 @@ def _stale(lib, srcs):
 
 def build(force=False):
     """Compiles oracle/libigw_oracle.so and oracle/libigw_trig_host.so (oracle/Makefile)."""
+    import fcntl
     src = [os.path.join(_HERE, f) for f in ('igw_oracle.c', 'igw_oracle.h', 'Makefile')]
-    if force or _stale(_LIB_PATH, src):
-        subprocess.run(['make', '-C', _HERE, '-B', 'libigw_oracle.so'], check=True,
-                       stdout=subprocess.DEVNULL)
     tsrc = [os.path.join(_HERE, 'igw_trig_host.cpp'), os.path.join(_CSRC, 'igw_trig.h'),
             os.path.join(_CSRC, 'igw_trig_tables.h')]
-    if force or _stale(_TRIG_PATH, tsrc):
-        subprocess.run(['make', '-C', _HERE, '-B', 'libigw_trig_host.so'], check=True,
-                       stdout=subprocess.DEVNULL)
+    if not (force or _stale(_LIB_PATH, src) or _stale(_TRIG_PATH, tsrc)):
+        return _LIB_PATH
+    with open(os.path.join(_HERE, '.build.lock'), 'w') as lock:  # several processes may start at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            for lib_path, deps, target in ((_LIB_PATH, src, 'libigw_oracle.so'),
+                                           (_TRIG_PATH, tsrc, 'libigw_trig_host.so')):
+                if force or _stale(lib_path, deps):  # re-checked under the lock
+                    subprocess.run(['make', '-C', _HERE, '-B', target], check=True, stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 
