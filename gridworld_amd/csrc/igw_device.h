@@ -323,8 +323,7 @@ struct Hit {
 };
 
 // Sample k is position + k sequential additions of vector/5 (the reference's recurrence, so the
-// rounding of every partial sum is reproduced); lane j of the group evaluates samples j, j+GS, ...
-// and a group ballot picks the first `key != previous and key in world`.
+// rounding of every partial sum is reproduced); the 40 samples are split over the lanes of the group.
 template <int GS>
 __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x, double y, double z,
                                double vx, double vy, double vz) {
@@ -352,45 +351,88 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
         }
         return h;
     } else {
-        constexpr int ROUNDS = (SAMPLES + GS - 1) / GS;
-        // pass 1: every lane walks to its samples (pure ALU) and issues all its membership probes
-        int key[ROUNDS];  // packed (kx+128) | (ky+128) << 8 | (kz+128) << 16
-        bool inw[ROUNDS];
-#pragma unroll
-        for (int r = 0; r < ROUNDS; r++) {
-            int nadd = (r == 0) ? G.gl : GS;
-            if (GS == 64) nadd = min(nadd, SAMPLES - 1);
-            const int bound = (r == 0) ? min(GS - 1, SAMPLES - 1) : GS;
-            if (r == 0) {
-                for (int i = 0; i < bound; i++) {
-                    if (i < nadd) { x = x + sx; y = y + sy; z = z + sz; }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < bound; i++) { x = x + sx; y = y + sy; z = z + sz; }
+        if constexpr (GS <= 2) {
+            // Lane j of the group owns the contiguous samples j*C .. j*C+C-1.  It first walks to its chunk
+            // (j*C sequential adds -- the reference's recurrence, nothing can be skipped), then evaluates its C
+            // samples; `previous` is lane-local except for the chunk's first sample (one shuffle), and the
+            // first `key != previous and key in world` of the whole ray is a per-lane scan + one group minimum.
+            constexpr int C = (SAMPLES + GS - 1) / GS;
+            const int lead = G.gl * C;  // samples in front of this lane's chunk
+            for (int i = 0; i < (GS - 1) * C && i < SAMPLES - 1; i++) {
+                if (i < lead) { x = x + sx; y = y + sy; z = z + sz; }
             }
-            const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
-            key[r] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
-            inw[r] = world_has(occ_s, kx, ky, kz);
-        }
-        // pass 2: `key != previous and key in world`, first sample wins
-        int last = 0;
-#pragma unroll
-        for (int r = 0; r < ROUNDS; r++) {
-            const int s = r * GS + G.gl;
-            int q = G.shfl_up1(key[r]);
-            if (G.gl == 0) q = last;
-            const bool cand = s < SAMPLES && ((s == 0) || key[r] != q) && inw[r];
-            const uint64_t m = G.ballot(cand);
-            if (m != 0 && !h.hit) {
-                const int first = __builtin_ctzll(m);
-                const int bk = G.bcast(key[r], first), pk = G.bcast(q, first);
+            int key[C];  // packed (kx+128) | (ky+128) << 8 | (kz+128) << 16
+            bool inw[C];
+    #pragma unroll
+            for (int k = 0; k < C; k++) {
+                const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
+                key[k] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
+                inw[k] = world_has(occ_s, kx, ky, kz);
+                if (k + 1 < C) { x = x + sx; y = y + sy; z = z + sz; }
+            }
+            int q = G.shfl_up1(key[C - 1]);  // last key of the previous lane's chunk = `previous` of our first sample
+            int first = SAMPLES, fkey = 0, fprev = 0;
+    #pragma unroll
+            for (int k = C - 1; k >= 0; k--) {  // descending, so the earliest candidate wins
+                const int s = lead + k;
+                const int prev = (k == 0) ? q : key[k - 1];
+                const bool cand = s < SAMPLES && ((s == 0) || key[k] != prev) && inw[k];
+                if (cand) { first = s; fkey = key[k]; fprev = prev; }
+            }
+            int best = first;
+    #pragma unroll
+            for (int o = GS / 2; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, GS));
+            if (best < SAMPLES) {
+                const int owner = best / C;
+                const int bk = G.bcast(fkey, owner), pk = G.bcast(fprev, owner);
                 h.hit = true;
-                h.have_prev = !(r == 0 && first == 0);
+                h.have_prev = best != 0;
                 h.bx = (bk & 0xff) - 128; h.by = ((bk >> 8) & 0xff) - 128; h.bz = ((bk >> 16) & 0xff) - 128;
                 h.px = (pk & 0xff) - 128; h.py = ((pk >> 8) & 0xff) - 128; h.pz = ((pk >> 16) & 0xff) - 128;
             }
-            if (r + 1 < ROUNDS) last = G.bcast(key[r], GS - 1);
+        } else {
+            // Strided mapping (lane j owns samples j, j+GS, ...): every round after the first advances all
+            // lanes by GS unmasked adds, which is cheaper than the chunked walk once groups are 4+ wide.
+            constexpr int ROUNDS = (SAMPLES + GS - 1) / GS;
+            // pass 1: every lane walks to its samples (pure ALU) and issues all its membership probes
+            int key[ROUNDS];  // packed (kx+128) | (ky+128) << 8 | (kz+128) << 16
+            bool inw[ROUNDS];
+    #pragma unroll
+            for (int r = 0; r < ROUNDS; r++) {
+                int nadd = (r == 0) ? G.gl : GS;
+                if (GS == 64) nadd = min(nadd, SAMPLES - 1);
+                const int bound = (r == 0) ? min(GS - 1, SAMPLES - 1) : GS;
+                if (r == 0) {
+                    for (int i = 0; i < bound; i++) {
+                        if (i < nadd) { x = x + sx; y = y + sy; z = z + sz; }
+                    }
+                } else {
+    #pragma unroll
+                    for (int i = 0; i < bound; i++) { x = x + sx; y = y + sy; z = z + sz; }
+                }
+                const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
+                key[r] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
+                inw[r] = world_has(occ_s, kx, ky, kz);
+            }
+            // pass 2: `key != previous and key in world`, first sample wins
+            int last = 0;
+    #pragma unroll
+            for (int r = 0; r < ROUNDS; r++) {
+                const int s = r * GS + G.gl;
+                int q = G.shfl_up1(key[r]);
+                if (G.gl == 0) q = last;
+                const bool cand = s < SAMPLES && ((s == 0) || key[r] != q) && inw[r];
+                const uint64_t m = G.ballot(cand);
+                if (m != 0 && !h.hit) {
+                    const int first = __builtin_ctzll(m);
+                    const int bk = G.bcast(key[r], first), pk = G.bcast(q, first);
+                    h.hit = true;
+                    h.have_prev = !(r == 0 && first == 0);
+                    h.bx = (bk & 0xff) - 128; h.by = ((bk >> 8) & 0xff) - 128; h.bz = ((bk >> 16) & 0xff) - 128;
+                    h.px = (pk & 0xff) - 128; h.py = ((pk >> 8) & 0xff) - 128; h.pz = ((pk >> 16) & 0xff) - 128;
+                }
+                if (r + 1 < ROUNDS) last = G.bcast(key[r], GS - 1);
+            }
         }
         return h;
     }
