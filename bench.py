@@ -174,7 +174,13 @@ def main():
 
     if rank != 0:
         return
-    lanes = env.cfg.lanes_per_env or (2 if flying else 4)
+    lanes = env.cfg.lanes_per_env
+    if not lanes:  # the library's automatic choice (include/igw.h: IGW_TARGET_WAVES)
+        lanes = 64
+        while lanes > 1 and N * lanes // 64 > 4096:
+            lanes //= 2
+        if flying and lanes > 1:
+            lanes //= 2
     p = (st1['changed'] - st0['changed']) / float(N * K)
     resets = st1['resets'] - st0['resets']
     bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4

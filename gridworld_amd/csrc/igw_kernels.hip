@@ -966,8 +966,15 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     if (cfg->action_space != IGW_WALKING_DISCRETE && cfg->action_space != IGW_FLYING &&
         cfg->action_space != IGW_WALKING_DICT)
         return fail(IGW_ERR_INVALID, "igw_create: unknown action_space");
-    int gs = cfg->lanes_per_env ? cfg->lanes_per_env
-                                : (cfg->action_space == IGW_FLYING ? IGW_DEFAULT_LANES_PER_ENV_FLYING : IGW_DEFAULT_LANES_PER_ENV);
+    int gs = cfg->lanes_per_env;
+    if (gs == 0) {
+        // auto: aim at ~IGW_TARGET_WAVES wavefronts per launch (4 per SIMD on MI355X) -- fewer leave the
+        // SIMDs without latency hiding, more only add redundant per-lane physics.  Measured optima:
+        // 4,096 envs -> 16..64 lanes, 16,384 -> 16, 65,536 -> 4, 262,144 -> 1.
+        gs = 64;
+        while (gs > 1 && (long long)cfg->num_envs * gs / 64 > IGW_TARGET_WAVES) gs >>= 1;
+        if (cfg->action_space == IGW_FLYING && gs > 1) gs >>= 1;  // heavier per-env arithmetic (general trig)
+    }
     if (gs != 64 && gs != 32 && gs != 16 && gs != 8 && gs != 4 && gs != 2 && gs != 1)
         return fail(IGW_ERR_INVALID, "igw_create: lanes_per_env must be 0 or a power of two in 1..64");
     int n = 0;

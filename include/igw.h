@@ -35,10 +35,10 @@ extern "C" {
 #endif
 
 #define IGW_VERSION 1
-/* lanes of a wavefront that cooperate on one env when igw_config.lanes_per_env == 0 (measured optimum
- * for per-step launches at 65,536 envs on MI355X; 64 = one wavefront per env) */
-#define IGW_DEFAULT_LANES_PER_ENV 4
-#define IGW_DEFAULT_LANES_PER_ENV_FLYING 2 /* heavier per-env arithmetic (general trig) favours narrower groups */
+/* igw_config.lanes_per_env == 0 picks the widest power-of-two lane group (64 = one wavefront per env ... 1 =
+ * one lane per env) that keeps a launch at or below this many wavefronts (4 per SIMD on MI355X); flying
+ * contexts take one step narrower.  65,536 envs -> 4 lanes per env. */
+#define IGW_TARGET_WAVES 4096
 
 /* dense voxel grid [y+1][x+5][z+5], int8 (env.py:34, 136-142) */
 #define IGW_GRID_Y 9
@@ -90,7 +90,7 @@ typedef struct igw_config {
     int32_t autoreset;         /* 0: caller resets on done (reference loop); 1: reset inside step */
     double right_placement_scale; /* env.py:335 */
     double wrong_placement_scale; /* env.py:337 */
-    int32_t lanes_per_env;     /* 0 = library default; 64,32,...,1: wavefront lanes cooperating on one env */
+    int32_t lanes_per_env;     /* 0 = automatic from num_envs (see IGW_TARGET_WAVES); or 64,32,...,1 */
     int32_t reserved;          /* must be 0 (timing-only ablation switches for profiling) */
 } igw_config;
 
