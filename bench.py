@@ -181,6 +181,8 @@ def main():
             lanes //= 2
         if flying and lanes > 1:
             lanes //= 2
+        elif not flying and lanes == 2:
+            lanes = 4
     p = (st1['changed'] - st0['changed']) / float(N * K)
     resets = st1['resets'] - st0['resets']
     bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4

@@ -314,6 +314,47 @@ __device__ inline void collide(Env& e, const uint32_t* occ_s, double& px, double
     }
 }
 
+// collide with the three axes spread over the lanes of a group (groups of 4+ lanes).  The reference visits
+// the faces in the order y+, y-, x-, x+, z+, z-; a face reads and writes only its own coordinate and its
+// probes depend only on np, so the axes are independent and only the two faces of one axis are ordered.
+// Lane (gl & 3) = 0 / 3 takes y, 1 takes x, 2 takes z, with exactly the reference's arithmetic; the three
+// results (and dy, which only the y faces clear) are then exchanged inside the group.
+template <int GS>
+__device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* occ_s, double& px, double& py,
+                                     double& pz) {
+    static_assert(GS >= 4, "needs three lanes per env");
+    const int nx = (int)__builtin_rint(px), ny = (int)__builtin_rint(py), nz = (int)__builtin_rint(pz);
+    const Probe w{occ_s, cell_of(nx, ny, nz), nx, ny, nz};
+    const int a = G.gl & 3;
+    const bool ax = a == 1, az = a == 2;
+    const int ux = ax ? 1 : 0, uz = az ? 1 : 0, uy = (ax || az) ? 0 : 1;
+    double pa = ax ? px : az ? pz : py;
+    const double na = (double)(ax ? nx : az ? nz : ny);
+    double vy = e.vy;
+    const int i1 = ax ? -1 : 1;          // first face of the axis: (0,1,0), (-1,0,0), (0,0,1)
+    const double f1 = ax ? -1.0 : 1.0;
+    double d = (pa - na) * f1;
+    if (!(d < PAD)) {
+        if (w.at(ux * i1, uy * i1, uz * i1) || w.at(ux * i1, uy * i1 - 1, uz * i1)) {
+            pa -= (d - PAD) * f1;
+            if (uy) vy = 0.0;
+        }
+    }
+    const int i2 = -i1;                  // second face: (0,-1,0), (1,0,0), (0,0,-1)
+    const double f2 = ax ? 1.0 : -1.0;
+    d = (pa - na) * f2;
+    if (!(d < PAD)) {
+        if (w.at(ux * i2, uy * i2, uz * i2) || w.at(ux * i2, uy * i2 - 1, uz * i2)) {
+            pa -= (d - PAD) * f2;
+            if (uy) vy = 0.0;
+        }
+    }
+    py = __shfl(pa, 0, 4);
+    px = __shfl(pa, 1, 4);
+    pz = __shfl(pa, 2, 4);
+    e.vy = __shfl(vy, 0, 4);
+}
+
 // ---------------------------------------------------------------- hit_test (core/world.py:73-99)
 
 struct Hit {
