@@ -179,9 +179,7 @@ def main():
         lanes = 64
         while lanes > 1 and N * lanes // 64 > 4096:
             lanes //= 2
-        if flying and lanes > 1:
-            lanes //= 2
-        elif not flying and lanes == 2:
+        if lanes == 2:
             lanes = 4
     p = (st1['changed'] - st0['changed']) / float(N * K)
     resets = st1['resets'] - st0['resets']

@@ -131,15 +131,37 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
         y = -90.0 > y ? -90.0 : y;
         e.pitch = y;
     }
-    // sin / cos of the (post-camera) pitch feed both the sight vector and, when flying, the motion vector:
-    // evaluate once (same argument => same value as the reference's two calls)
-    double sp = 0.0, cp = 1.0;
+    // The step needs up to three sin/cos pairs, all of the post-camera rotation: pitch (sight vector and,
+    // when flying, motion vector -- one evaluation serves both, same argument => same value), yaw - 90
+    // (sight vector) and yaw + strafe heading (motion vector).  They are independent, so in groups of 4+
+    // lanes each is evaluated by one lane (same code, argument chosen by lane) and exchanged.
     const bool want_sight = add != remove && !(p.debug & 2);
-    if (want_sight || (FLY && (s0 != 0.0 || s1 != 0.0))) sincos_deg(trig, e.pitch, sp, cp);
+    const bool strafing = s0 != 0.0 || s1 != 0.0;
+    double strafe_deg = 0.0;
+    if (strafing) {  // math.degrees(math.atan2(*agent.strafe)), :176
+        if (!FLY && s1 == 0.0) strafe_deg = s0 < 0.0 ? -90.0 : 90.0;       // degrees(atan2(-+1, 0))
+        else if (!FLY && s0 == 0.0) strafe_deg = s1 < 0.0 ? 180.0 : 0.0;   // degrees(atan2(0, -+1))
+        else strafe_deg = igw_atan2(s0, s1) * D180_OVER_PI;
+    }
+    const bool want_pitch = want_sight || (FLY && strafing);
+    double sp = 0.0, cp = 1.0, sy = 0.0, cy = 1.0, sx = 0.0, cx = 1.0;
+    if constexpr (GS >= 4) {
+        const int a = G.gl & 3;
+        const double deg = a == 1 ? e.yaw - 90.0 : a == 2 ? e.yaw + strafe_deg : e.pitch;
+        const bool need = a == 1 ? want_sight : a == 2 ? strafing : want_pitch;
+        double sv = 0.0, cv = 1.0;
+        if (need) sincos_deg(trig, deg, sv, cv);
+        sp = __shfl(sv, 0, 4); cp = __shfl(cv, 0, 4);
+        sy = __shfl(sv, 1, 4); cy = __shfl(cv, 1, 4);
+        sx = __shfl(sv, 2, 4); cx = __shfl(cv, 2, 4);
+    } else {
+        if (want_pitch) sincos_deg(trig, e.pitch, sp, cp);
+        if (want_sight) sincos_deg(trig, e.yaw - 90.0, sy, cy);
+        if (strafing) sincos_deg(trig, e.yaw + strafe_deg, sx, cx);
+    }
     // place_or_remove_block, :312-332
     if (want_sight) {
-        double sy, cy;                           // m = cos(radians(y)); dy = sin(radians(y))
-        sincos_deg(trig, e.yaw - 90.0, sy, cy);  // dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
+        // m = cos(radians(y)); dy = sin(radians(y)); dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
         const double vx = cy * cp, vy = sp, vz = sy * cp;
         const Hit h = hit_test<GS>(G, occ_s, e.x, e.y, e.z, vx, vy, vz);
         if (add) {
@@ -187,13 +209,7 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
         const double dt = m == 2 ? 0.05 / 2 : m == 4 ? 0.05 / 4 : m == 8 ? 0.05 / 8 : 0.05 / 12;
         // get_motion_vector, :163-201 (rotation and strafe are constant over the sub-steps)
         double mvx = 0.0, mvy = 0.0, mvz = 0.0;
-        if (s0 != 0.0 || s1 != 0.0) {
-            double strafe_deg;
-            if (!FLY && s1 == 0.0) strafe_deg = s0 < 0.0 ? -90.0 : 90.0;       // degrees(atan2(-+1, 0))
-            else if (!FLY && s0 == 0.0) strafe_deg = s1 < 0.0 ? 180.0 : 0.0;   // degrees(atan2(0, -+1))
-            else strafe_deg = igw_atan2(s0, s1) * D180_OVER_PI;
-            double sx, cx;
-            sincos_deg(trig, e.yaw + strafe_deg, sx, cx);
+        if (strafing) {
             if (FLY) {
                 double mm = cp;
                 mvy = sp;
@@ -974,11 +990,7 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
         // 4,096 envs -> 16..64 lanes, 16,384 -> 16, 65,536 -> 4, 262,144 -> 1.
         gs = 64;
         while (gs > 1 && (long long)cfg->num_envs * gs / 64 > IGW_TARGET_WAVES) gs >>= 1;
-        if (cfg->action_space == IGW_FLYING) {
-            if (gs > 1) gs >>= 1;  // heavier per-env arithmetic (general trig) favours narrower groups
-        } else if (gs == 2) {
-            gs = 4;                // 4 lanes unlock the axis-split collide; measured faster than 2 at every N
-        }
+        if (gs == 2) gs = 4;  // 4 lanes unlock the lane-split collide / trig; measured faster than 2 at every N
     }
     if (gs != 64 && gs != 32 && gs != 16 && gs != 8 && gs != 4 && gs != 2 && gs != 1)
         return fail(IGW_ERR_INVALID, "igw_create: lanes_per_env must be 0 or a power of two in 1..64");

@@ -36,9 +36,8 @@ extern "C" {
 
 #define IGW_VERSION 1
 /* igw_config.lanes_per_env == 0 picks the widest power-of-two lane group (64 = one wavefront per env ... 1 =
- * one lane per env) that keeps a launch at or below this many wavefronts (4 per SIMD on MI355X); flying
- * contexts take one step narrower, walking contexts never take 2 (4 lanes unlock the axis-split collide).
- * 65,536 envs -> 4 lanes per env. */
+ * one lane per env) that keeps a launch at or below this many wavefronts (4 per SIMD on MI355X), except
+ * that 2 is never chosen (4 lanes unlock the lane-split collide and trig).  65,536 envs -> 4 lanes per env. */
 #define IGW_TARGET_WAVES 4096
 
 /* dense voxel grid [y+1][x+5][z+5], int8 (env.py:34, 136-142) */
