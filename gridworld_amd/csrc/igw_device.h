@@ -224,6 +224,13 @@ __device__ inline bool world_has(const uint32_t* occ_s, int x, int y, int z) {
     if (!build_zone_i(x, y, z)) return false;
     return occ_test(occ_s, cell_of(x, y, z));
 }
+// same without control flow (the bitmap word is always read, index clamped to 0 outside the zone): used
+// where the lanes of a wave disagree on the outcome anyway and branches only cost exec-mask bookkeeping
+__device__ inline bool world_has_nobranch(const uint32_t* occ_s, int x, int y, int z) {
+    const bool ground = y == -2 && (unsigned)(x + 18) <= 36u && (unsigned)(z + 18) <= 36u;
+    const bool in = build_zone_i(x, y, z);
+    return (int)ground | ((int)in & (int)occ_test(occ_s, in ? cell_of(x, y, z) : 0));
+}
 
 // ---------------------------------------------------------------- trig front-end
 
@@ -273,6 +280,14 @@ struct Probe {
         if (y == -2) return x >= -18 && x <= 18 && z >= -18 && z <= 18;
         const bool in = (unsigned)(x + 5) <= 10u && (unsigned)(z + 5) <= 10u && (unsigned)(y + 1) <= 8u;
         return in && occ_test(occ_s, base + dy * LEVEL + dx * 11 + dz);
+    }
+    // same without control flow: the bitmap word is always read (index clamped to 0 when out of range)
+    __device__ bool at_nobranch(int dx, int dy, int dz) const {
+        const int x = nx + dx, y = ny + dy, z = nz + dz;
+        const bool ground = y == -2 && (unsigned)(x + 18) <= 36u && (unsigned)(z + 18) <= 36u;
+        const bool in = (unsigned)(x + 5) <= 10u && (unsigned)(z + 5) <= 10u && (unsigned)(y + 1) <= 8u;
+        const int idx = in ? base + dy * LEVEL + dx * 11 + dz : 0;
+        return (int)ground | ((int)in & (int)occ_test(occ_s, idx));
     }
 };
 
@@ -333,22 +348,19 @@ __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* o
     double vy = e.vy;
     const int i1 = ax ? -1 : 1;          // first face of the axis: (0,1,0), (-1,0,0), (0,0,1)
     const double f1 = ax ? -1.0 : 1.0;
-    double d = (pa - na) * f1;
-    if (!(d < PAD)) {
-        if (w.at(ux * i1, uy * i1, uz * i1) || w.at(ux * i1, uy * i1 - 1, uz * i1)) {
-            pa -= (d - PAD) * f1;
-            if (uy) vy = 0.0;
-        }
-    }
+    // predicated instead of branched: lanes of a wave disagree on almost every one of these tests, so the
+    // branches bought nothing and cost exec-mask bookkeeping; the selects keep the arithmetic identical
     const int i2 = -i1;                  // second face: (0,-1,0), (1,0,0), (0,0,-1)
     const double f2 = ax ? 1.0 : -1.0;
+    const bool b1 = (int)w.at_nobranch(ux * i1, uy * i1, uz * i1) | (int)w.at_nobranch(ux * i1, uy * i1 - 1, uz * i1);
+    const bool b2 = (int)w.at_nobranch(ux * i2, uy * i2, uz * i2) | (int)w.at_nobranch(ux * i2, uy * i2 - 1, uz * i2);
+    double d = (pa - na) * f1;
+    const bool h1 = !(d < PAD) && b1;
+    pa = h1 ? pa - (d - PAD) * f1 : pa;
     d = (pa - na) * f2;
-    if (!(d < PAD)) {
-        if (w.at(ux * i2, uy * i2, uz * i2) || w.at(ux * i2, uy * i2 - 1, uz * i2)) {
-            pa -= (d - PAD) * f2;
-            if (uy) vy = 0.0;
-        }
-    }
+    const bool h2 = !(d < PAD) && b2;
+    pa = h2 ? pa - (d - PAD) * f2 : pa;
+    if (uy && (h1 || h2)) vy = 0.0;
     py = __shfl(pa, 0, 4);
     px = __shfl(pa, 1, 4);
     pz = __shfl(pa, 2, 4);
@@ -408,7 +420,7 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
             for (int k = 0; k < C; k++) {
                 const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
                 key[k] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
-                inw[k] = world_has(occ_s, kx, ky, kz);
+                inw[k] = world_has_nobranch(occ_s, kx, ky, kz);
                 if (k + 1 < C) { x = x + sx; y = y + sy; z = z + sz; }
             }
             int q = G.shfl_up1(key[C - 1]);  // last key of the previous lane's chunk = `previous` of our first sample
@@ -453,26 +465,33 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
                 }
                 const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
                 key[r] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
-                inw[r] = world_has(occ_s, kx, ky, kz);
+                inw[r] = world_has_nobranch(occ_s, kx, ky, kz);
             }
-            // pass 2: `key != previous and key in world`, first sample wins
-            int last = 0;
-    #pragma unroll
-            for (int r = 0; r < ROUNDS; r++) {
+            // pass 2: `key != previous and key in world`, first sample wins.  Every lane scans its own samples
+            // (previous = the neighbouring lane's key of the same round, or the last lane's key of the round
+            // before), then one group minimum picks the earliest candidate: no ballot / branch per round.
+            int first = SAMPLES, fkey = 0, fprev = 0;
+#pragma unroll
+            for (int r = ROUNDS - 1; r >= 0; r--) {  // descending, so the earliest candidate wins
                 const int s = r * GS + G.gl;
                 int q = G.shfl_up1(key[r]);
-                if (G.gl == 0) q = last;
-                const bool cand = s < SAMPLES && ((s == 0) || key[r] != q) && inw[r];
-                const uint64_t m = G.ballot(cand);
-                if (m != 0 && !h.hit) {
-                    const int first = __builtin_ctzll(m);
-                    const int bk = G.bcast(key[r], first), pk = G.bcast(q, first);
-                    h.hit = true;
-                    h.have_prev = !(r == 0 && first == 0);
-                    h.bx = (bk & 0xff) - 128; h.by = ((bk >> 8) & 0xff) - 128; h.bz = ((bk >> 16) & 0xff) - 128;
-                    h.px = (pk & 0xff) - 128; h.py = ((pk >> 8) & 0xff) - 128; h.pz = ((pk >> 16) & 0xff) - 128;
+                if (r > 0) {
+                    const int wrap = G.bcast(key[r - 1], GS - 1);
+                    if (G.gl == 0) q = wrap;
                 }
-                if (r + 1 < ROUNDS) last = G.bcast(key[r], GS - 1);
+                const bool cand = s < SAMPLES && ((s == 0) || key[r] != q) && inw[r];
+                if (cand) { first = s; fkey = key[r]; fprev = q; }
+            }
+            int best = first;
+#pragma unroll
+            for (int o = GS / 2; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, GS));
+            if (best < SAMPLES) {
+                const int owner = best % GS;
+                const int bk = G.bcast(fkey, owner), pk = G.bcast(fprev, owner);
+                h.hit = true;
+                h.have_prev = best != 0;
+                h.bx = (bk & 0xff) - 128; h.by = ((bk >> 8) & 0xff) - 128; h.bz = ((bk >> 16) & 0xff) - 128;
+                h.px = (pk & 0xff) - 128; h.py = ((pk >> 8) & 0xff) - 128; h.pz = ((pk >> 16) & 0xff) - 128;
             }
         }
         return h;
