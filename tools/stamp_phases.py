@@ -3,7 +3,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from gridworld_amd import VecGridWorld, workloads
 N = 65536
-for gs in (4, 2, 8):
+for gs in (4,):
     env = VecGridWorld(N, size_reward=False, autoreset=True, lanes_per_env=gs)
     env.set_tasks(workloads.rt20(N, seed=0, device=env.device)); env.reset()
     acts = env.fill_actions(120, seed=1)
