@@ -252,6 +252,13 @@ __device__ inline void sincos_deg(const TrigCtx& t, double deg, double& s, doubl
     }
 }
 
+// normalize(): int(round(x)), round-half-even (gridworld/utils.py:57-73), as ONE f64 add: adding
+// 1.5 * 2^52 leaves the integer nearest to x (ties to even, default rounding mode) in the low mantissa
+// bits, i.e. in the low dword in two's complement.  Exact for |x| < 2^31; positions here stay within +-40.
+__device__ inline int rint_i32(double x) {
+    return __double2loint(x + 0x1.8p52);
+}
+
 // x / 5 exactly as IEEE division rounds it, in 3 flops instead of a full f64 division sequence:
 // q0 = RN(x * RN(1/5)), r = x - 5 q0 (exact in an fma), q = RN(q0 + r * RN(1/5)) is the correctly rounded
 // quotient (Markstein's theorem; checked bit-for-bit against x / 5.0 on 4*10^8 arguments).  Zeros and
@@ -294,7 +301,7 @@ struct Probe {
 // Six faces in the reference order; a face only probes when its overlap test passes.  (Issuing all 12
 // probes up front -- they depend only on np -- was measured slower at every group size.)
 __device__ inline void collide(Env& e, const uint32_t* occ_s, double& px, double& py, double& pz) {
-    const int nx = (int)__builtin_rint(px), ny = (int)__builtin_rint(py), nz = (int)__builtin_rint(pz);
+    const int nx = rint_i32(px), ny = rint_i32(py), nz = rint_i32(pz);
     const Probe w{occ_s, cell_of(nx, ny, nz), nx, ny, nz};
     double d;
     d = (py - (double)ny) * 1.0;  // face (0, 1, 0): heights dy = 0, 1 probe (nx, ny - dy + 1, nz)
@@ -338,7 +345,7 @@ template <int GS>
 __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* occ_s, double& px, double& py,
                                      double& pz) {
     static_assert(GS >= 4, "needs three lanes per env");
-    const int nx = (int)__builtin_rint(px), ny = (int)__builtin_rint(py), nz = (int)__builtin_rint(pz);
+    const int nx = rint_i32(px), ny = rint_i32(py), nz = rint_i32(pz);
     const Probe w{occ_s, cell_of(nx, ny, nz), nx, ny, nz};
     const int a = G.gl & 3;
     const bool ax = a == 1, az = a == 2;
@@ -390,7 +397,7 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
         // one lane per env: the reference loop as is; stop when every active lane has its answer
         int qx = 0, qy = 0, qz = 0;
         for (int s = 0; s < SAMPLES; s++) {
-            const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
+            const int kx = rint_i32(x), ky = rint_i32(y), kz = rint_i32(z);
             const bool differs = (s == 0) || kx != qx || ky != qy || kz != qz;
             if (!h.hit && differs && world_has(occ_s, kx, ky, kz)) {
                 h.hit = true;
@@ -418,7 +425,7 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
             bool inw[C];
     #pragma unroll
             for (int k = 0; k < C; k++) {
-                const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
+                const int kx = rint_i32(x), ky = rint_i32(y), kz = rint_i32(z);
                 key[k] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
                 inw[k] = world_has_nobranch(occ_s, kx, ky, kz);
                 if (k + 1 < C) { x = x + sx; y = y + sy; z = z + sz; }
@@ -463,7 +470,7 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
     #pragma unroll
                     for (int i = 0; i < bound; i++) { x = x + sx; y = y + sy; z = z + sz; }
                 }
-                const int kx = (int)__builtin_rint(x), ky = (int)__builtin_rint(y), kz = (int)__builtin_rint(z);
+                const int kx = rint_i32(x), ky = rint_i32(y), kz = rint_i32(z);
                 key[r] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
                 inw[r] = world_has_nobranch(occ_s, kx, ky, kz);
             }
