@@ -97,6 +97,21 @@ struct KParams {
 
 // ---------------------------------------------------------------- lane groups
 
+// Fixed cross-lane patterns inside a quad (4 consecutive lanes) as DPP moves: one VALU instruction instead
+// of a trip through the LDS crossbar (ds_bpermute).  CTRL = quad_perm: bits [2i+1:2i] = source lane of lane i.
+template <int CTRL>
+__device__ inline int dpp_quad(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ inline double dpp_quad(double v) {
+    const int lo = dpp_quad<CTRL>(__double2loint(v)), hi = dpp_quad<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+constexpr int QUAD_BCAST0 = 0x00, QUAD_BCAST1 = 0x55, QUAD_BCAST2 = 0xAA, QUAD_BCAST3 = 0xFF;
+constexpr int QUAD_SHIFT_UP = 0x90;  // lane i <- lane i-1, lane 0 keeps its own value
+constexpr int QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E;
+
 template <int GS>
 struct Grp {
     static constexpr int NG = WAVE / GS;
@@ -123,7 +138,24 @@ struct Grp {
     }
     __device__ int shfl_up1(int v) const {
         if constexpr (GS == 1) return v;
+        else if constexpr (GS == 4) return dpp_quad<QUAD_SHIFT_UP>(v);
         else return __shfl_up(v, 1, GS);
+    }
+    // value of the group's last lane
+    __device__ int bcast_last(int v) const {
+        if constexpr (GS == 1) return v;
+        else if constexpr (GS == 4) return dpp_quad<QUAD_BCAST3>(v);
+        else return bcast(v, GS - 1);
+    }
+    __device__ int group_min(int v) const {
+        if constexpr (GS == 4) {
+            v = min(v, dpp_quad<QUAD_XOR2>(v));
+            return min(v, dpp_quad<QUAD_XOR1>(v));
+        } else {
+#pragma unroll
+            for (int o = GS / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, GS));
+            return v;
+        }
     }
 };
 
@@ -368,10 +400,10 @@ __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* o
     const bool h2 = !(d < PAD) && b2;
     pa = h2 ? pa - (d - PAD) * f2 : pa;
     if (uy && (h1 || h2)) vy = 0.0;
-    py = __shfl(pa, 0, 4);
-    px = __shfl(pa, 1, 4);
-    pz = __shfl(pa, 2, 4);
-    e.vy = __shfl(vy, 0, 4);
+    py = dpp_quad<QUAD_BCAST0>(pa);
+    px = dpp_quad<QUAD_BCAST1>(pa);
+    pz = dpp_quad<QUAD_BCAST2>(pa);
+    e.vy = dpp_quad<QUAD_BCAST0>(vy);
 }
 
 // ---------------------------------------------------------------- hit_test (core/world.py:73-99)
@@ -483,15 +515,13 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
                 const int s = r * GS + G.gl;
                 int q = G.shfl_up1(key[r]);
                 if (r > 0) {
-                    const int wrap = G.bcast(key[r - 1], GS - 1);
+                    const int wrap = G.bcast_last(key[r - 1]);
                     if (G.gl == 0) q = wrap;
                 }
                 const bool cand = s < SAMPLES && ((s == 0) || key[r] != q) && inw[r];
                 if (cand) { first = s; fkey = key[r]; fprev = q; }
             }
-            int best = first;
-#pragma unroll
-            for (int o = GS / 2; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, GS));
+            const int best = G.group_min(first);
             if (best < SAMPLES) {
                 const int owner = best % GS;
                 const int bk = G.bcast(fkey, owner), pk = G.bcast(fprev, owner);

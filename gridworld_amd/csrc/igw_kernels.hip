@@ -151,9 +151,9 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
         const bool need = a == 1 ? want_sight : a == 2 ? strafing : want_pitch;
         double sv = 0.0, cv = 1.0;
         if (need) sincos_deg(trig, deg, sv, cv);
-        sp = __shfl(sv, 0, 4); cp = __shfl(cv, 0, 4);
-        sy = __shfl(sv, 1, 4); cy = __shfl(cv, 1, 4);
-        sx = __shfl(sv, 2, 4); cx = __shfl(cv, 2, 4);
+        sp = dpp_quad<QUAD_BCAST0>(sv); cp = dpp_quad<QUAD_BCAST0>(cv);
+        sy = dpp_quad<QUAD_BCAST1>(sv); cy = dpp_quad<QUAD_BCAST1>(cv);
+        sx = dpp_quad<QUAD_BCAST2>(sv); cx = dpp_quad<QUAD_BCAST2>(cv);
     } else {
         if (want_pitch) sincos_deg(trig, e.pitch, sp, cp);
         if (want_sight) sincos_deg(trig, e.yaw - 90.0, sy, cy);
