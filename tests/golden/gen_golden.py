@@ -234,6 +234,19 @@ def main():
     wd = dict(buttons=b, camera=cam)
     save('s8_walk_dict', kw, tg, [[]] * E, wd, H.run_batch(kw, tg, [[]] * E, wd))
 
+    # S9 -- select_and_place=False (GridWorld's own default; hotbar only selects, core/world.py:444-446)
+    rng = np.random.RandomState(909)
+    E, T = 8, 300
+    pairs = [cdm_with_start(rng, goals, names) for _ in range(4)]
+    tg = np.stack([rt20(rng) for _ in range(4)] + [p[0] for p in pairs])
+    st = [[]] * 4 + [p[1] for p in pairs]
+    acts = rng.choice(18, size=(E, T), p=np.array([1] * 14 + [3] + [1] + [2, 3]) / 23.0)
+    kw = dict(size_reward=False, select_and_place=False)
+    save('s9_walk_no_select_and_place', kw, tg, st, acts, H.run_batch(kw, tg, st, acts))
+    fa = flying_actions(rng, 6, 300)
+    kw = dict(size_reward=False, select_and_place=False, action_space='flying')
+    save('s9_fly_no_select_and_place', kw, tg[:6], st[:6], fa, H.run_batch(kw, tg[:6], st[:6], fa))
+
     # S6 -- pure Task vectors: admissible sets, rotations, maximal / argmax intersection
     rng = np.random.RandomState(606)
     targets = [np.zeros((9, 11, 11), np.int8), dummy, two]

@@ -19,8 +19,9 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 WALK_FIXTURES = ['s1_walk_dummy', 's1_walk_dummy_sizereward', 's2_walk_cdm', 's2_walk_cdm_sizereward',
-                 's3_walk_rt20', 's5_scripted', 's5_scripted_scales', 's5_scripted_leak', 's5_init_pose']
-FLY_FIXTURES = ['s4_fly_rt20', 's4_fly_cdm']
+                 's3_walk_rt20', 's5_scripted', 's5_scripted_scales', 's5_scripted_leak', 's5_init_pose',
+                 's9_walk_no_select_and_place']
+FLY_FIXTURES = ['s4_fly_rt20', 's4_fly_cdm', 's9_fly_no_select_and_place']
 DICT_FIXTURES = ['s8_walk_dict']
 
 

@@ -42,10 +42,13 @@ def test_gloo_world2_sharding_and_reduction(tmp_path):
     import json
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)]
     env = dict(os.environ, OMP_NUM_THREADS='1')
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    for attempt in range(3):  # the free port can be taken between the probe and the rendezvous
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        if out.returncode == 0:
+            break
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
