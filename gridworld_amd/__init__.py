@@ -4,7 +4,7 @@
     import gridworld_amd; env = gridworld_amd.make('IGLUGridworld-v0', vector_state=True, render=False)
 """
 from ._lib import IgwError  # noqa: F401
-from .vec_env import VecGridWorld, task_eval  # noqa: F401
+from .vec_env import SubBatch, VecGridWorld, task_eval  # noqa: F401
 
 __version__ = '0.1.0'
 from .env import GridWorld, create_env, make, make_vec  # noqa: F401,E402

@@ -209,6 +209,18 @@ class VecGridWorld:
                                                   int(env_offset), self._stream()), 'igw_fill_actions_walking')
         return a
 
+    # ---- asynchronous sub-batches ----
+    def split(self, parts, streams=None):
+        """`parts` contiguous sub-batches that SHARE this env's tensors (each is a view of rows
+        [lo, hi)) but have their own context and HIP stream, so they can be stepped independently --
+        e.g. policy inference on one half overlaps env stepping of the other (EnvPool-style async mode).
+        Envs are independent, so results are identical to stepping the whole batch."""
+        if self.num_envs % parts:
+            raise ValueError('num_envs must be divisible by parts')
+        n = self.num_envs // parts
+        streams = streams or [torch.cuda.Stream(device=self.device) for _ in range(parts)]
+        return [SubBatch(self, k * n, n, streams[k]) for k in range(parts)]
+
     # ---- introspection ----
     def stats(self):
         s = self.stats_buf.sum(0).cpu()
@@ -232,6 +244,51 @@ class VecGridWorld:
                 'prev_size': (raw[:, 52:54].copy().view(np.uint16)[:, 0] & 0x7fff).astype(np.int64),
                 'dirty': (raw[:, 52:54].copy().view(np.uint16)[:, 0] >> 15).astype(np.int64),
                 'max_int': raw[:, 54:56].copy().view(np.int16)[:, 0].astype(np.int64)}
+
+
+class SubBatch:
+    """Rows [lo, lo + n) of a VecGridWorld behind their own igw context and stream (VecGridWorld.split)."""
+
+    def __init__(self, parent, lo, n, stream):
+        self.parent, self.lo, self.num_envs, self.stream = parent, lo, n, stream
+        self.lib, self.device = parent.lib, parent.device
+        cfg = L.Config.from_buffer_copy(parent.cfg)
+        cfg.num_envs = n
+        self.cfg = cfg
+        self.ctx = C.c_void_p()
+        L.check(self.lib.igw_create(C.byref(cfg), C.byref(self.ctx)), 'igw_create')
+        per_env = (parent.grid_buf, parent.occ_buf, parent.hist_buf, parent.agent_buf, parent.env_task)
+        shared = (parent.task_target, parent.task_start, parent.task_start_occ, parent.task_meta)
+        outs = (parent.agent_pos, parent.inventory, parent.compass, parent.reward, parent.done)
+        self.stats_buf = torch.zeros_like(parent.stats_buf)
+        ptrs = [t[lo:lo + n].data_ptr() for t in per_env] + [t.data_ptr() for t in shared] + \
+               [t[lo:lo + n].data_ptr() for t in outs] + [self.stats_buf.data_ptr()]
+        L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(L.Buffers(*ptrs))), 'igw_bind_buffers')
+        sl = slice(lo, lo + n)
+        self.agent_pos, self.inventory = parent.agent_pos[sl], parent.inventory[sl]
+        self.compass, self.reward, self.done = parent.compass[sl], parent.reward[sl], parent.done[sl]
+        self.grid = parent.grid[sl]
+
+    def __del__(self):
+        if getattr(self, 'ctx', None):
+            self.lib.igw_destroy(self.ctx)
+            self.ctx = None
+
+    def obs(self):
+        return {'agentPos': self.agent_pos, 'inventory': self.inventory, 'compass': self.compass.unsqueeze(1),
+                'grid': self.grid}
+
+    def step_walking_ptr(self, actions_i32):
+        """actions_i32: contiguous int32 device tensor [n]; launched on this sub-batch's stream."""
+        L.check(self.lib.igw_step_walking(self.ctx, actions_i32.data_ptr(), C.c_void_p(self.stream.cuda_stream)),
+                'igw_step_walking')
+
+    def reset(self):
+        L.check(self.lib.igw_reset(self.ctx, None, 0, C.c_void_p(self.stream.cuda_stream)), 'igw_reset')
+        return self.obs()
+
+    def synchronize(self):
+        self.stream.synchronize()
 
 
 def task_eval(targets, grids, full_grids=None, invariant=None, device='cuda:0'):

@@ -100,3 +100,34 @@ def test_state_dict_roundtrip():
     for k, v in final.items():
         if k != 'stats_buf':
             assert torch.equal(v, getattr(env2, k)), k
+
+
+def test_sub_batches_on_streams_equal_whole_batch():
+    """VecGridWorld.split: free-running sub-batches on their own streams give the same bytes as one batch."""
+    from gridworld_amd import VecGridWorld, workloads
+    n, T = 8192, 150
+    tg = workloads.rt20(n, seed=12)
+
+    def make():
+        env = VecGridWorld(n, autoreset=True, size_reward=False, max_steps=60)
+        env.set_tasks(tg.to(env.device))
+        env.reset()
+        return env
+    whole, parts_env = make(), make()
+    acts = whole.fill_actions(T, seed=4)
+    for t in range(T):
+        whole.step_walking_ptr(acts[t])
+    torch.cuda.synchronize()
+    subs = parts_env.split(4)
+    m = n // 4
+    chunks = [acts[:, k * m:(k + 1) * m].contiguous() for k in range(4)]
+    torch.cuda.synchronize()
+    for t in range(T):
+        for k, sb in enumerate(subs):
+            sb.step_walking_ptr(chunks[k][t])
+    for sb in subs:
+        sb.synchronize()
+    for a, b in ((whole.grid_buf, parts_env.grid_buf), (whole.agent_buf, parts_env.agent_buf),
+                 (whole.hist_buf, parts_env.hist_buf), (whole.reward, parts_env.reward),
+                 (whole.agent_pos, parts_env.agent_pos)):
+        assert torch.equal(a, b)
