@@ -234,6 +234,18 @@ def main():
     wd = dict(buttons=b, camera=cam)
     save('s8_walk_dict', kw, tg, [[]] * E, wd, H.run_batch(kw, tg, [[]] * E, wd))
 
+    # S4c -- flying with the reference's trig replaced by correctly rounded sin/cos/atan2 ("CR-libm oracle")
+    rng = np.random.RandomState(414)
+    E, T = 8, 300
+    pairs = [cdm_with_start(rng, goals, names) for _ in range(4)]
+    tg = np.stack([rt20(rng) for _ in range(4)] + [p[0] for p in pairs])
+    st = [[]] * 4 + [p[1] for p in pairs]
+    fa = flying_actions(rng, E, T)
+    fa['movement'][:, ::9, rng.randint(3)] = 0.0   # exact zeros / axis-aligned strafes
+    kw = dict(size_reward=False, action_space='flying')
+    with H.cr_libm():
+        save('s4_fly_crlibm', kw, tg, st, fa, H.run_batch(kw, tg, st, fa))
+
     # S9 -- select_and_place=False (GridWorld's own default; hotbar only selects, core/world.py:444-446)
     rng = np.random.RandomState(909)
     E, T = 8, 300

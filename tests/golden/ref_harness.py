@@ -41,6 +41,45 @@ def load_reference():
     return gym, Task, Tasks
 
 
+class _CRMath:
+    """Drop-in for the `math` module inside gridworld.core.world with CORRECTLY ROUNDED sin / cos / atan2
+    (mpmath, 300 bits -> nearest double); everything else is the real `math`.  "CR-libm oracle" mode of
+    SURVEY.md section 8a: against such a reference a correctly rounded implementation matches on every bit."""
+
+    def __init__(self):
+        import math
+        import mpmath
+        self._math, self._mp = math, mpmath
+        mpmath.mp.prec = 300
+
+    def __getattr__(self, name):
+        return getattr(self._math, name)
+
+    def sin(self, x):
+        return x if x == 0 else float(self._mp.sin(self._mp.mpf(float(x))))
+
+    def cos(self, x):
+        return float(self._mp.cos(self._mp.mpf(float(x))))
+
+    def atan2(self, y, x):
+        if y == 0 or x == 0:
+            return self._math.atan2(y, x)  # exact special values (signed zeros, +-pi/2, +-pi)
+        return float(self._mp.atan2(self._mp.mpf(float(y)), self._mp.mpf(float(x))))
+
+
+class cr_libm:
+    """with cr_libm(): ... -- the reference's world module computes with correctly rounded trig."""
+
+    def __enter__(self):
+        load_reference()
+        import gridworld.core.world as w
+        self._w, self._old = w, w.math
+        w.math = _CRMath()
+
+    def __exit__(self, *a):
+        self._w.math = self._old
+
+
 def dense_to_sparse(dense):
     """dense [9,11,11] -> reference-style sparse list [(x, y, z, id)] (tasks/task.py:178-187)."""
     out = []

@@ -28,6 +28,16 @@ def test_flying_fixture_reference_trig(name):
     print(f'{name}: {n_bits} of {len(fin)} envs end with a last-bit float64 difference vs glibc')
 
 
+@pytest.mark.parametrize('gs', [0, 64, 1])
+def test_flying_fixture_cr_libm_reference_bit_exact(gs):
+    """Against the Python reference run with correctly rounded trig ("CR-libm oracle" mode) the HIP path
+    matches on EVERY bit: float32 observations, integer outputs and the float64 agent internals."""
+    from hip_driver import HipDriver
+    for name in GR.CRLIBM_FIXTURES:
+        fx = GR.load_fixture(name)
+        assert GR.replay(fx, HipDriver(fx, lanes_per_env=gs), check_internal=True) == fx['done'].size
+
+
 def test_walking_dict_fixture_reference_trig():
     """discretize=False walking (buttons + continuous camera): same contract as flying vs the reference."""
     from hip_driver import HipDriver

@@ -106,3 +106,17 @@ def test_oracle_device_trig_mode_switch():
         O.use_device_trig(False)
     # same trajectory up to last-bit trig differences
     assert np.allclose(a[:6], fx['internal'][0, 49][:6], rtol=0, atol=1e-9)
+
+
+def test_oracle_device_trig_replays_cr_libm_reference_bit_for_bit():
+    """"CR-libm oracle" (SURVEY.md section 8a): the Python reference run with correctly rounded sin/cos/atan2.
+    The build's trig is correctly rounded, so the oracle with that trig reproduces the whole trajectory --
+    float64 internals included -- which pins igw_trig.h to the reference's call sites, not just to mpmath."""
+    import golden_replay as GR
+    try:
+        O.use_device_trig(True)
+        for name in GR.CRLIBM_FIXTURES:
+            fx = GR.load_fixture(name)
+            assert GR.replay(fx, GR.OracleDriver(fx), check_internal=True) == fx['done'].size
+    finally:
+        O.use_device_trig(False)
