@@ -246,6 +246,17 @@ def main():
     with H.cr_libm():
         save('s4_fly_crlibm', kw, tg, st, fa, H.run_batch(kw, tg, st, fa))
 
+    rng = np.random.RandomState(818)   # the same for walking with discretize=False
+    E, T = 6, 300
+    tg = np.stack([rt20(rng) for _ in range(4)] + [cdm_with_start(rng, goals, names)[0] for _ in range(2)])
+    b = (rng.rand(E, T, 8) < 0.3).astype(np.uint8)
+    b[:, :, 7] = rng.randint(0, 7, size=(E, T)) * (rng.rand(E, T) < 0.3)
+    cam = rng.uniform(-5, 5, size=(E, T, 2)).astype(np.float32)
+    kw = dict(size_reward=False, discretize=False)
+    wd = dict(buttons=b, camera=cam)
+    with H.cr_libm():
+        save('s8_walk_dict_crlibm', kw, tg, [[]] * E, wd, H.run_batch(kw, tg, [[]] * E, wd))
+
     # S9 -- select_and_place=False (GridWorld's own default; hotbar only selects, core/world.py:444-446)
     rng = np.random.RandomState(909)
     E, T = 8, 300

@@ -24,7 +24,7 @@ WALK_FIXTURES = ['s1_walk_dummy', 's1_walk_dummy_sizereward', 's2_walk_cdm', 's2
 FLY_FIXTURES = ['s4_fly_rt20', 's4_fly_cdm', 's9_fly_no_select_and_place']
 DICT_FIXTURES = ['s8_walk_dict']
 # recorded with the reference's sin/cos/atan2 replaced by correctly rounded ones (ref_harness.cr_libm)
-CRLIBM_FIXTURES = ['s4_fly_crlibm']
+CRLIBM_FIXTURES = ['s4_fly_crlibm', 's8_walk_dict_crlibm']
 
 
 def load_fixture(name):
