@@ -131,3 +131,60 @@ def test_sub_batches_on_streams_equal_whole_batch():
                  (whole.hist_buf, parts_env.hist_buf), (whole.reward, parts_env.reward),
                  (whole.agent_pos, parts_env.agent_pos)):
         assert torch.equal(a, b)
+
+
+def test_step_loop_is_graph_capturable():
+    """The C ABI never synchronises or allocates, so a K-step loop can be captured into a HIP graph and
+    replayed; the replay produces the same bytes as eager launches."""
+    from gridworld_amd import VecGridWorld, workloads
+    n, K = 4096, 40
+    tg = workloads.rt20(n, seed=21)
+
+    def make():
+        env = VecGridWorld(n, autoreset=True, size_reward=False, max_steps=30)
+        env.set_tasks(tg.to(env.device))
+        env.reset()
+        return env
+    eager, graphed = make(), make()
+    acts = eager.fill_actions(K, seed=9)
+    for t in range(K):
+        eager.step_walking_ptr(acts[t])
+    acts_g = graphed.fill_actions(K, seed=9)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    snap = graphed.state_dict()
+    with torch.cuda.graph(g):
+        for t in range(K):
+            graphed.step_walking_ptr(acts_g[t])
+    graphed.load_state_dict(snap)   # capture does not execute; start the replay from the same state
+    graphed.stats_buf.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eager.grid_buf, graphed.grid_buf) and torch.equal(eager.agent_buf, graphed.agent_buf)
+    assert torch.equal(eager.hist_buf, graphed.hist_buf) and torch.equal(eager.reward, graphed.reward)
+
+
+def test_shared_and_partially_updated_task_table():
+    """Many envs share a small task table through env_task; rows can be replaced in place (set_tasks first=)."""
+    from gridworld_amd import VecGridWorld, workloads
+    from oracle import oracle as O
+    n, ntasks, T = 600, 5, 80
+    tg = workloads.rt20(ntasks + 2, seed=41).numpy()
+    mapping = (np.arange(n) * 7 % ntasks).astype(np.int32)
+    env = VecGridWorld(n, num_tasks=ntasks, size_reward=False, max_steps=500)
+    env.set_tasks(tg[:ntasks], env_task=mapping)
+    env.set_tasks(tg[ntasks:ntasks + 2], first=1)          # replace rows 1 and 2
+    table = tg[:ntasks].copy()
+    table[1:3] = tg[ntasks:ntasks + 2]
+    env.reset()
+    ob = O.OracleBatch(n, size_reward=False, max_steps=500)
+    ob.set_tasks(table[mapping])
+    ob.reset()
+    acts = env.fill_actions(T, seed=2).cpu().numpy()
+    for t in range(T):
+        env.step(torch.as_tensor(acts[t]))
+        ob.step_walking(acts[t], nthreads=8)
+    torch.cuda.synchronize()
+    assert np.array_equal(env.grid.cpu().numpy().reshape(n, -1), ob.grid)
+    assert np.array_equal(env.reward.cpu().numpy(), ob.reward)
+    assert np.array_equal(env.internals().view(np.uint64), ob.internals().view(np.uint64))
