@@ -2,8 +2,10 @@
 """Headline benchmark: env-steps/sec of the vectorised env.step() hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no torchrun environment, bench.py starts its own N ranks (one per GPU) as a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` BEFORE touching
+the GPU and relays rank 0's JSON line; launched under torchrun it is a rank.
 
 One "step" = one igw_step_walking launch over every env of the rank (one env.step() per env, reward
 and done included, auto-reset of finished episodes inside the launch).  Workload = BASELINE.json
@@ -11,28 +13,105 @@ configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block 
 maximal_intersection reward), uniform random actions that are already resident in HBM when the timed
 region starts.  Weak scaling: every rank owns its own 65,536 envs; no data-path collective.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Steady state before the clock: episodes are de-synchronised (every env starts at a random step of its
+episode, then one untimed 250-step pre-roll), so any timed window -- also a 20-step one -- sees the
+steady-state fraction of grid-changing steps and about N/250 auto-resets per launch.  The K timed
+launches are captured into ONE HIP graph (instantiated before the clock) and replayed inside the
+barrier / synchronize bracket, so a short window is kernel-bound, not host-launch-bound (--no-graph
+times the eager launches instead).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     -- HBM roofline of the dominant kernel from ALGORITHMIC bytes per env-step
                   (1274 + 1106 * p bytes, p = measured fraction of env-steps
                   whose block count changed) over the kernel's average duration (HIP events on the
-                  launch stream);
+                  launch stream); `traffic` / `hbm_measured_gbs` = PMC bytes of the committed profile;
+  issue        -- the instruction-issue side (the real limiter): VALU instructions per
+                  env-step and per wave from the committed SQ counter profile, waves per SIMD;
   cpu_baseline -- the CPU oracle (plain-C port of the reference algorithm) timed on the host cores on
                   a bounded sample of the same workload (N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 ENVS_PER_GPU = 65536
+MAX_STEPS = 250
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 BYTES_BASE, BYTES_CHANGED = 1274, 1106  # SURVEY.md section 8d
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--lanes-per-env', type=int, default=0)
+    ap.add_argument('--seed', type=int, default=2024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fused', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of one HIP-graph replay')
+    ap.add_argument('--lockstep', action='store_true',
+                    help='skip the episode de-synchronisation (round-1 behaviour: all envs at the same episode step)')
+    ap.add_argument('--mode', choices=['walking', 'flying'], default='walking',
+                    help='walking = BASELINE configs[2] (headline); flying = configs[3]')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / rendezvous check without a GPU: ranks reduce fake counters over gloo')
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: become the launcher.  This process never touches the GPU; the N
+    ranks are children of torch.distributed.run and rank 0's JSON line is relayed to our stdout."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    rc = 1
+    for attempt in range(3):  # the probed port can be taken before the rendezvous binds it
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+        got = False
+        for line in proc.stdout:
+            if line.startswith('{'):
+                sys.stdout.write(line)
+                sys.stdout.flush()
+                got = True
+            else:
+                sys.stderr.write(line)
+        rc = proc.wait()
+        if rc == 0 and got:
+            return 0
+        if got:
+            break
+    return rc or 1
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def cpu_baseline(seed):
@@ -63,75 +142,109 @@ def cpu_baseline(seed):
     t = time.perf_counter()
     s1, _ = b1.rollout_walking(250, seed, autoreset=True, nthreads=1)
     dt1 = time.perf_counter() - t
-    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'cpu_model': cpu_model(), 'kind': 'port',
             'sample': f'{n} envs x {T} steps, rt20 targets, counter-RNG uniform actions, resets included '
                       f'({dt:.1f} s on {cores} threads)',
             'value_1core': s1 / dt1, 'sample_1core': f'{n1} envs x 250 steps ({dt1:.1f} s)',
             'p_changed': changed / max(steps, 1)}
 
 
-def load_traffic():
-    """HBM bytes per launch from the committed PMC profile (profiles/*traffic*.json), or None."""
+def load_profile(suffix):
+    """Latest committed profile summary profiles/*<suffix> (json), or None."""
     import glob
     best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic.json'))):
+    for p in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix))):
         try:
             with open(p) as f:
                 best = json.load(f)
+            best['_file'] = os.path.relpath(p, ROOT)
         except Exception:
             pass
     return best
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=500)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
-    ap.add_argument('--lanes-per-env', type=int, default=0)
-    ap.add_argument('--seed', type=int, default=2024)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-fused', action='store_true')
-    ap.add_argument('--debug-flags', type=int, default=0, help='timing-only ablations (results invalid)')
-    ap.add_argument('--mode', choices=['walking', 'flying'], default='walking',
-                    help='walking = BASELINE configs[2] (headline); flying = configs[3]')
-    args = ap.parse_args()
+def auto_lanes(n):
+    """The library's automatic group width (include/igw.h: IGW_TARGET_WAVES)."""
+    lanes = 64
+    while lanes > 1 and n * lanes // 64 > 4096:
+        lanes //= 2
+    return 4 if lanes == 2 else lanes
 
+
+def dry_run(args):
+    """No GPU: proves the launcher brought up `world` ranks that can rendezvous and reduce."""
+    from gridworld_amd import dist as gdist
+    rank, local_rank, world = gdist.init(backend='gloo')
+    gdist.barrier()
+    total, mx = gdist.reduce_window(args.envs_per_gpu * args.steps, 1e-3 * (rank + 1))
+    ranks = gdist.gather_counts(rank)
+    if rank == 0:
+        print(json.dumps({'metric': 'dry-run', 'n_gpus': world, 'ranks': ranks, 'total_steps': total,
+                          'max_elapsed': mx, 'steps': args.steps, 'warmup': args.warmup}))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.dry_run:
+        return dry_run(args)
+
+    import torch
     from gridworld_amd import VecGridWorld, dist as gdist, workloads
     rank, local_rank, world = gdist.init()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    # one process per GPU; IGW_SHARE_GPU=1 lets several ranks share one device (CI on a 1-GPU box, gloo)
+    # one process per GPU; IGW_SHARE_GPU=1 lets several ranks share one device (CI on a 1-GPU box)
     device = torch.device('cuda', 0 if os.environ.get('IGW_SHARE_GPU') else local_rank)
     torch.cuda.set_device(device)
     N, K, W = args.envs_per_gpu, args.steps, args.warmup
     env_offset = rank * N  # rank-offset RNG streams / task seeds
 
     flying = args.mode == 'flying'
-    env = VecGridWorld(N, device=device, action_space=args.mode, size_reward=False, max_steps=250,
-                       autoreset=True, lanes_per_env=args.lanes_per_env, debug_flags=args.debug_flags)
+    env = VecGridWorld(N, device=device, action_space=args.mode, size_reward=False, max_steps=MAX_STEPS,
+                       autoreset=True, lanes_per_env=args.lanes_per_env)
     env.set_tasks(workloads.rt20(N, seed=args.seed + rank, device=device))
     env.reset()
-    # actions for warmup + timed steps are generated on the device before the clock starts
+    g = torch.Generator(device=device)
+    g.manual_seed(args.seed + 7919 * rank)
+    if not args.lockstep:
+        # every env starts at a random step of its episode (GridWorld.step_no, agent record bytes 48..49)
+        sn = torch.randint(0, MAX_STEPS, (N,), generator=g, device=device, dtype=torch.int32)
+        env.agent_buf[:, 48] = (sn & 0xff).to(torch.uint8)
+        env.agent_buf[:, 49] = (sn >> 8).to(torch.uint8)
+
+    # actions for pre-roll, warmup and the timed steps are generated on the device before the clock starts
     if flying:
-        if args.no_fused is False:
-            args.no_fused = True  # the fused rollout kernel is walking-only
-        g = torch.Generator(device=device)
-        g.manual_seed(args.seed + 7919 * rank)
-        mv = torch.rand((W + K, N, 3), generator=g, device=device) * 2 - 1      # movement ~ U(-1, 1)^3
-        cam = torch.rand((W + K, N, 2), generator=g, device=device) * 10 - 5    # camera ~ U(-5, 5)^2
-        inv = torch.randint(0, 7, (W + K, N), generator=g, device=device, dtype=torch.int32)
-        plc = torch.randint(0, 3, (W + K, N), generator=g, device=device, dtype=torch.int32)
-        import ctypes as C
+        args.no_fused = True  # the fused rollout kernel is walking-only
         from gridworld_amd import _lib as L
 
+        def fly_actions(n_steps):
+            mv = torch.rand((n_steps, N, 3), generator=g, device=device) * 2 - 1      # movement ~ U(-1, 1)^3
+            cam = torch.rand((n_steps, N, 2), generator=g, device=device) * 10 - 5    # camera ~ U(-5, 5)^2
+            inv = torch.randint(0, 7, (n_steps, N), generator=g, device=device, dtype=torch.int32)
+            plc = torch.randint(0, 3, (n_steps, N), generator=g, device=device, dtype=torch.int32)
+            return mv, cam, inv, plc
+
+        def fly_step(a, t):
+            L.check(env.lib.igw_step_flying(env.ctx, a[0][t].data_ptr(), a[1][t].data_ptr(), a[2][t].data_ptr(),
+                                            a[3][t].data_ptr(), env._stream()), 'igw_step_flying')
+        if not args.lockstep:
+            for _ in range(MAX_STEPS // 50):  # untimed pre-roll to the steady state
+                pre = fly_actions(50)
+                for t in range(50):
+                    fly_step(pre, t)
+            torch.cuda.synchronize(device)
+            del pre
+        acts = fly_actions(W + K)
+
         def step(t):
-            L.check(env.lib.igw_step_flying(env.ctx, mv[t].data_ptr(), cam[t].data_ptr(), inv[t].data_ptr(),
-                                            plc[t].data_ptr(), env._stream()), 'igw_step_flying')
+            fly_step(acts, t)
     else:
+        if not args.lockstep:
+            env.rollout(MAX_STEPS, seed=args.seed + 17, t0=0, env_offset=env_offset)  # untimed pre-roll
         chunk = 256
         actions = [env.fill_actions(min(chunk, W + K - t0), seed=args.seed, t0=t0, env_offset=env_offset)
                    for t0 in range(0, W + K, chunk)]
@@ -142,14 +255,29 @@ def main():
     for t in range(W):
         step(t)
     torch.cuda.synchronize(device)
+    graph = None
+    if not args.no_graph:
+        # The K timed launches as one HIP graph.  Capture records the launches without running them (the
+        # entry points never synchronise or allocate), instantiation happens here, before the clock.
+        graph = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(device=device)
+        cap.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.graph(graph, stream=cap):
+            for t in range(W, W + K):
+                step(t)
+        torch.cuda.current_stream(device).wait_stream(cap)
+        torch.cuda.synchronize(device)
     st0 = env.stats()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     gdist.barrier(device)
     torch.cuda.synchronize(device)
     t_start = time.perf_counter()
     ev0.record()
-    for t in range(W, W + K):
-        step(t)
+    if graph is not None:
+        graph.replay()
+    else:
+        for t in range(W, W + K):
+            step(t)
     ev1.record()
     torch.cuda.synchronize(device)
     gdist.barrier(device)
@@ -157,6 +285,7 @@ def main():
     st1 = env.stats()
     kernel_ms = ev0.elapsed_time(ev1) / K
     total_steps, max_elapsed = gdist.reduce_window(N * K, elapsed, device)
+    n_ranks = len(gdist.gather_counts(rank, device))
 
     # secondary: fused T-step rollout (state resident in LDS/registers, in-kernel RNG)
     fused = None
@@ -174,23 +303,19 @@ def main():
 
     if rank != 0:
         return
-    lanes = env.cfg.lanes_per_env
-    if not lanes:  # the library's automatic choice (include/igw.h: IGW_TARGET_WAVES)
-        lanes = 64
-        while lanes > 1 and N * lanes // 64 > 4096:
-            lanes //= 2
-        if lanes == 2:
-            lanes = 4
+    lanes = env.cfg.lanes_per_env or auto_lanes(N)
     p = (st1['changed'] - st0['changed']) / float(N * K)
     resets = st1['resets'] - st0['resets']
     bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4
     achieved = N * bytes_per_step / (kernel_ms * 1e-3) / 1e9
-    traffic = load_traffic()
+    traffic = None if flying else load_profile('traffic.json')
+    issue = None if flying else load_profile('issue.json')
+    hbm_bytes = None if traffic is None else traffic.get('hbm_bytes_per_launch')
     out = {
         'metric': 'env-steps/sec (render=False, vector_state) at N parallel envs, 1/2/4/8 GPU',
         'value': total_steps / max_elapsed,
         'unit': 'env-steps/s',
-        'n_gpus': world,
+        'n_gpus': n_ranks,
         'steps': K,
         'warmup': W,
         'ms_per_step': max_elapsed / K * 1e3,
@@ -205,18 +330,25 @@ def main():
                                ('configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block '
                                 'targets (rt20), full maximal_intersection reward, uniform random actions, '
                                 'auto-reset at done (max_steps=250)'),
-                   'envs_per_gpu': N, 'total_envs': N * world, 'lanes_per_env': lanes,
-                   'launches_per_step': 1, 'resets_in_window': resets, 'p_changed': p,
+                   'envs_per_gpu': N, 'total_envs': N * n_ranks, 'lanes_per_env': lanes,
+                   'launches_per_step': 1, 'timed_as': 'eager launches' if graph is None else 'one HIP-graph replay of K launches',
+                   'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + 250-step pre-roll)',
+                   'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': None if traffic is None else traffic.get('hbm_bytes_per_launch'),
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': hbm_bytes,
                      'kernel': 'igw::step_kernel<%d, %d>' % (lanes, 1 if flying else 0), 'kernel_avg_ms': kernel_ms,
                      'algorithmic_bytes_per_env_step': bytes_per_step,
-                     'algorithmic_bytes_per_launch': N * bytes_per_step},
+                     'algorithmic_bytes_per_launch': N * bytes_per_step,
+                     # what the memory system really moved (committed PMC profile) over this run's kernel time:
+                     # the kernel is latency / issue bound, not HBM bound -- see `issue` and DESIGN.md section 5
+                     'hbm_measured_gbs': None if hbm_bytes is None else hbm_bytes / (kernel_ms * 1e-3) / 1e9,
+                     'hbm_measured_frac': None if hbm_bytes is None else hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     'traffic_profile': None if traffic is None else traffic.get('_file')},
     }
-    if flying:
-        out['roofline']['traffic'] = None  # the committed PMC profile is for the walking kernel
+    if issue is not None:
+        out['issue'] = {k: v for k, v in issue.items() if not k.startswith('_') and k != 'raw'}
+        out['issue']['profile'] = issue.get('_file')
     if world == 1 and not args.no_cpu_baseline and not flying:
         out['cpu_baseline'] = cpu_baseline(args.seed)
     print(json.dumps(out))

@@ -5,6 +5,7 @@ entry point raises.
 """
 import ctypes as C
 import os
+import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libigw_hip.so')
@@ -49,20 +50,25 @@ _lib = None
 
 
 def load(build_if_missing=True):
-    """Loads libigw_hip.so (building it with hipcc first if it is missing or stale)."""
+    """Loads libigw_hip.so (building it with hipcc first if it is missing or stale).  IGW_DIAG=1 in the
+    environment selects the diagnostic build (phase stamps, ablation switches) -- tools/ only."""
     global _lib
     if _lib is not None:
         return _lib
+    diag = os.environ.get('IGW_DIAG') == '1'
+    path = os.path.join(HERE, 'libigw_hip_diag.so') if diag else LIB_PATH
     if build_if_missing:
         from . import build as _build
         try:
-            _build.build()
-        except Exception as e:  # stale .so + no hipcc is still usable; a missing .so is fatal
-            if not os.path.exists(LIB_PATH):
-                raise IgwError(f'libigw_hip.so is missing and could not be built: {e}') from e
-    if not os.path.exists(LIB_PATH):
-        raise IgwError('libigw_hip.so not found; run `python -m gridworld_amd.build`')
-    L = C.CDLL(LIB_PATH)
+            _build.build(diag=diag)
+        except subprocess.CalledProcessError as e:  # a compile error must never fall back to a stale binary
+            raise IgwError(f'hipcc failed to build {os.path.basename(path)}: {e}') from e
+        except Exception as e:  # no hipcc: an existing library is still usable, a missing one is fatal
+            if not os.path.exists(path):
+                raise IgwError(f'{os.path.basename(path)} is missing and could not be built: {e}') from e
+    if not os.path.exists(path):
+        raise IgwError(f'{os.path.basename(path)} not found; run `python -m gridworld_amd.build`')
+    L = C.CDLL(path)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     L.igw_version.restype = C.c_int
     L.igw_last_error.restype = C.c_char_p

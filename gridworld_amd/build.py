@@ -14,8 +14,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libigw_hip.so')
+LIB_DIAG = os.path.join(HERE, 'libigw_hip_diag.so')  # -DIGW_DIAG: phase stamps + ablation switches (tools/ only)
 SOURCES = ['igw_kernels.hip']
-HEADERS = ['igw_device.h', 'igw_trig.h', 'igw_trig_lut.h', os.path.join('..', '..', 'include', 'igw.h')]
+HEADERS = ['igw_device.h', 'igw_trig.h', 'igw_trig_lut.h', 'igw_trig_tables.h',
+           os.path.join('..', '..', 'include', 'igw.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-variable']
 
@@ -27,35 +29,39 @@ def hipcc():
     raise RuntimeError('hipcc not found')
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def is_stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, extra_flags=(), verbose=False):
+def build(force=False, extra_flags=(), verbose=False, diag=False):
     """Compiles under an exclusive file lock and installs the result with an atomic rename, so several
-    ranks starting at once (torchrun) never see or write a half-built library."""
-    if not force and not is_stale():
-        return LIB
+    ranks starting at once (torchrun) never see or write a half-built library.  diag=True builds the
+    diagnostic variant (libigw_hip_diag.so, -DIGW_DIAG) next to the production library."""
+    lib = LIB_DIAG if diag else LIB
+    if diag:
+        extra_flags = tuple(extra_flags) + ('-DIGW_DIAG',)
+    if not force and not is_stale(lib):
+        return lib
     import fcntl
-    with open(LIB + '.lock', 'w') as lock:
+    with open(lib + '.lock', 'w') as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not is_stale():  # another process built it while we waited
-                return LIB
-            tmp = f'{LIB}.tmp.{os.getpid()}'
+            if not force and not is_stale(lib):  # another process built it while we waited
+                return lib
+            tmp = f'{lib}.tmp.{os.getpid()}'
             cmd = [hipcc()] + FLAGS + list(extra_flags) + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
             if verbose:
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True)
-            os.replace(tmp, LIB)
+            os.replace(tmp, lib)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, diag='--diag' in sys.argv))

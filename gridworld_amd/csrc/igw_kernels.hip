@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "igw_device.h"
@@ -37,8 +38,12 @@ struct StepOut {
     bool done;
 };
 
-// In-kernel phase stamps (diagnostic only, never in a timed run): drain this wave's memory queues so the
-// time is charged to the phase that caused the wait, then read the shader clock.
+// In-kernel phase stamps exist only in the diagnostic build of the library (-DIGW_DIAG, libigw_hip_diag.so,
+// tools/stamp_phases.py): drain this wave's memory queues so the time is charged to the phase that caused
+// the wait, then read the shader clock.  The production library compiles them (and the timing-only
+// ablation switches of igw_config.reserved) out.
+#ifdef IGW_DIAG
+#define IGW_DIAG_FLAG(p, bit) ((p).debug & (bit))
 __device__ inline void stamp(const KParams& p, int slot) {
     if (p.stamps) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -46,6 +51,15 @@ __device__ inline void stamp(const KParams& p, int slot) {
         if (__lane_id() == 0) p.stamps[((size_t)blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE) * 8 + slot] = t;
     }
 }
+// slot 7: what this wave had to do (changed envs, rescans, resets, longest sub-step count), for tail analysis
+__device__ inline void stamp_features(const KParams& p, unsigned long long v) {
+    if (p.stamps && __lane_id() == 0) p.stamps[((size_t)blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE) * 8 + 7] = v;
+}
+#else
+#define IGW_DIAG_FLAG(p, bit) 0
+__device__ inline void stamp(const KParams&, int) {}
+__device__ inline void stamp_features(const KParams&, unsigned long long) {}
+#endif
 
 __device__ inline void stat_add(unsigned long long* stats, int which, unsigned long long v) {
     if (stats) atomicAdd(&stats[(blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + which], v);
@@ -135,7 +149,7 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
     // when flying, motion vector -- one evaluation serves both, same argument => same value), yaw - 90
     // (sight vector) and yaw + strafe heading (motion vector).  They are independent, so in groups of 4+
     // lanes each is evaluated by one lane (same code, argument chosen by lane) and exchanged.
-    const bool want_sight = add != remove && !(p.debug & 2);
+    const bool want_sight = add != remove && !IGW_DIAG_FLAG(p, 2);
     const bool strafing = s0 != 0.0 || s1 != 0.0;
     double strafe_deg = 0.0;
     if (strafing) {  // math.degrees(math.atan2(*agent.strafe)), :176
@@ -223,7 +237,7 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
                 mvz = sx;
             }
         }
-        for (int i = 0; i < ((p.debug & 4) ? 0 : m); i++) {  // _update, :222-262
+        for (int i = 0; i < (IGW_DIAG_FLAG(p, 4) ? 0 : m); i++) {  // _update, :222-262
             const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
             const double d = dt * speed;
             const double ddx = mvx * d, ddz = mvz * d;
@@ -515,11 +529,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     bool need = false, has_start = false;
     const TaskMeta* meta = nullptr;
     int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
+    [[maybe_unused]] int diag_m = 0;  // IGW_DIAG: sub-steps this env asked for
     if (active) {
         task = p.env_task[env];  // prefetched: only consumed if the grid changes or the episode ends
         env_load(e, p.agent + env);
         wave_sync();
         stamp(p, 1);
+        diag_m = e.tis;
         e.step_no = min(e.step_no + 1, 65535);  // env.py:276
         if (MODE == MODE_WALK) {
             ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, a.actions[env]);
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     stamp(p, 4);
     int incmax = 0;
     bool decd = false;
-    const bool changed = active && ch.idx >= 0 && !(p.debug & 1);
+    const bool changed = active && ch.idx >= 0 && !IGW_DIAG_FLAG(p, 1);
     resolve_changes<GS, false>(G, p, sh.ws[wave], changed, env, task, ch, e.max_int, incmax, decd);
     size_new = e.prev_size;
     if (active && ch.idx >= 0) {
@@ -583,6 +599,15 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
         }
     }
     resolve_resets<GS>(G, p, do_reset, env, task, has_start, nullptr);
+#ifdef IGW_DIAG
+    {
+        const unsigned long long n_ch = __builtin_popcountll(__ballot(changed && G.gl == 0));
+        const unsigned long long n_rs = __builtin_popcountll(__ballot(rescan && G.gl == 0));
+        const unsigned long long n_rt = __builtin_popcountll(__ballot(do_reset && G.gl == 0));
+        const unsigned long long n_hit = __builtin_popcountll(__ballot(ch.idx >= 0 && ch.new_val == 0 && G.gl == 0));
+        stamp_features(p, n_ch | (n_rs << 8) | (n_rt << 16) | ((unsigned long long)wave_max_i32(diag_m) << 24) | (n_hit << 32));
+    }
+#endif
     if (!active) return;
     if (do_reset) reset_env_regs(e, meta, false);
     if (G.gl == 0) {
@@ -953,14 +978,16 @@ struct DeviceGuard {
     }
 };
 
-static hipError_t upload_lut() {
-    static thread_local int done_for = -1;
-    int dev = -1;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (done_for == dev) return hipSuccess;
-    e = hipMemcpyToSymbol(HIP_SYMBOL(IGW_TRIG_LUT_DEV), IGW_TRIG_LUT_HOST, sizeof(IGW_TRIG_LUT_HOST));
-    if (e == hipSuccess) done_for = dev;
+// The walking trig table goes to constant memory once per device and process, at igw_create (the step
+// entry points never copy or synchronise, so they stay legal inside a HIP-graph capture).
+static std::mutex g_lut_mutex;
+static bool g_lut_done[64];
+
+static hipError_t upload_lut(int dev) {
+    std::lock_guard<std::mutex> lock(g_lut_mutex);
+    if (dev >= 0 && dev < 64 && g_lut_done[dev]) return hipSuccess;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(IGW_TRIG_LUT_DEV), IGW_TRIG_LUT_HOST, sizeof(IGW_TRIG_LUT_HOST));
+    if (e == hipSuccess && dev >= 0 && dev < 64) g_lut_done[dev] = true;
     return e;
 }
 
@@ -992,6 +1019,10 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
         while (gs > 1 && (long long)cfg->num_envs * gs / 64 > IGW_TARGET_WAVES) gs >>= 1;
         if (gs == 2) gs = 4;  // 4 lanes unlock the lane-split collide / trig; measured faster than 2 at every N
     }
+#ifndef IGW_DIAG
+    if (cfg->reserved != 0)
+        return fail(IGW_ERR_INVALID, "igw_create: reserved must be 0 (ablation switches exist only in the IGW_DIAG build)");
+#endif
     if (gs != 64 && gs != 32 && gs != 16 && gs != 8 && gs != 4 && gs != 2 && gs != 1)
         return fail(IGW_ERR_INVALID, "igw_create: lanes_per_env must be 0 or a power of two in 1..64");
     int n = 0;
@@ -1015,7 +1046,7 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     {
         DeviceGuard g(cfg->device);
         if (!g.ok) { delete c; return fail(IGW_ERR_HIP, "igw_create: hipSetDevice failed"); }
-        hipError_t e = upload_lut();
+        hipError_t e = upload_lut(cfg->device);
         if (e != hipSuccess) { delete c; return fail(IGW_ERR_HIP, "igw_create: LUT upload: %s", hipGetErrorString(e)); }
     }
     *out = c;
@@ -1032,8 +1063,13 @@ int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed) {
 
 int igw_debug_set_stamps(igw_ctx* ctx, uint64_t* stamps) {
     if (!ctx) return fail(IGW_ERR_INVALID, "igw_debug_set_stamps: null context");
+#ifdef IGW_DIAG
     ctx->kp.stamps = reinterpret_cast<unsigned long long*>(stamps);
     return IGW_OK;
+#else
+    (void)stamps;
+    return fail(IGW_ERR_INVALID, "igw_debug_set_stamps: only available in the IGW_DIAG build (libigw_hip_diag.so)");
+#endif
 }
 
 int igw_destroy(igw_ctx* ctx) {
@@ -1073,8 +1109,7 @@ int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
     if (!ctx) return fail(IGW_ERR_INVALID, name ": null context");             \
     if (!ctx->bound) return fail(IGW_ERR_UNBOUND, name ": buffers not bound"); \
     DeviceGuard guard(ctx->cfg.device);                                        \
-    if (!guard.ok) return fail(IGW_ERR_HIP, name ": hipSetDevice failed");     \
-    HIP_TRY(upload_lut())
+    if (!guard.ok) return fail(IGW_ERR_HIP, name ": hipSetDevice failed")
 
 #define DISPATCH_GS(gs, CALL)          \
     switch (gs) {                      \

@@ -64,3 +64,20 @@ def test_shard_envs_partition():
             edges = [shard_envs(total, r, world) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == total
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` (no torchrun) must bring up 2 ranks itself: the launcher path, exercised
+    without a GPU through --dry-run (ranks rendezvous over gloo and reduce fake counters)."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5',
+                          '--dry-run'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks'] == [0, 1]
+    assert d['total_steps'] == 2 * 65536 * 20 and d['steps'] == 20 and d['warmup'] == 5

@@ -1,29 +1,70 @@
-"""Diagnostic: per-wave phase durations of the walking step kernel from in-kernel s_memtime stamps."""
-import sys, numpy as np, torch
-sys.path.insert(0, '.')
-from gridworld_amd import VecGridWorld, workloads
+#!/usr/bin/env python3
+"""Diagnostic (IGW_DIAG build only): per-wave phase durations of the walking step kernel from in-kernel
+s_memtime stamps, in the de-synchronised steady state bench.py times, with per-wave work features
+(changed envs, rescans, resets, sub-steps) so the launch's tail can be attributed.
+
+    IGW_DIAG=1 python tools/stamp_phases.py [out.npz] [lanes_per_env]
+"""
+import os
+import sys
+
+os.environ['IGW_DIAG'] = '1'
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from gridworld_amd import VecGridWorld, workloads  # noqa: E402
+
 N = 65536
-for gs in (4,):
-    env = VecGridWorld(N, size_reward=False, autoreset=True, lanes_per_env=gs)
-    env.set_tasks(workloads.rt20(N, seed=0, device=env.device)); env.reset()
-    acts = env.fill_actions(120, seed=1)
-    for t in range(100): env.step_walking_ptr(acts[t])
-    waves = N * gs // 64
-    st = torch.zeros((waves, 8), dtype=torch.int64, device=env.device)
-    env.lib.igw_debug_set_stamps(env.ctx, st.data_ptr())
-    acc = []
-    for t in range(100, 120):
-        st.zero_(); env.step_walking_ptr(acts[t]); torch.cuda.synchronize()
-        a = st.cpu().numpy().astype(np.float64)
-        acc.append(a)
-    a = np.stack(acc)  # [20, waves, 8]
-    t0 = a[:, :, 0].min(axis=1, keepdims=True)
-    names = ['start->loads', 'act+hit_test', 'physics', 'tail of world_step', 'changes', 'rescan/finish/stores']
-    d = np.diff(a[:, :, :7], axis=2)
-    print(f'GS {gs}: waves {waves}; clock ticks (100 MHz s_memtime? raw units)')
-    print('  first wave start -> last wave end:', (a[:, :, 6].max(1) - a[:, :, 0].min(1)).mean())
-    print('  wave start spread (last start - first start):', (a[:, :, 0].max(1) - a[:, :, 0].min(1)).mean())
-    print('  wave lifetime mean / p50 / p99 / max:', (a[:, :, 6] - a[:, :, 0]).mean(), np.percentile(a[:, :, 6] - a[:, :, 0], 50), np.percentile(a[:, :, 6] - a[:, :, 0], 99), (a[:, :, 6] - a[:, :, 0]).max())
-    for i, nme in enumerate(names):
-        print(f'  {nme:24s} mean {d[:, :, i].mean():9.1f}  p99 {np.percentile(d[:, :, i], 99):9.1f}  max {d[:, :, i].max():9.1f}')
-    env.lib.igw_debug_set_stamps(env.ctx, None)
+out = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/stamps.npz'
+gs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+env = VecGridWorld(N, size_reward=False, autoreset=True, lanes_per_env=gs)
+env.set_tasks(workloads.rt20(N, seed=0, device=env.device))
+env.reset()
+g = torch.Generator(device=env.device)
+g.manual_seed(1)
+sn = torch.randint(0, 250, (N,), generator=g, device=env.device, dtype=torch.int32)
+env.agent_buf[:, 48] = (sn & 0xff).to(torch.uint8)
+env.agent_buf[:, 49] = (sn >> 8).to(torch.uint8)
+env.rollout(250, seed=3)
+acts = env.fill_actions(60, seed=1)
+for t in range(20):
+    env.step_walking_ptr(acts[t])
+waves = N * gs // 64
+st = torch.zeros((waves, 8), dtype=torch.int64, device=env.device)
+env.lib.igw_debug_set_stamps(env.ctx, st.data_ptr())
+acc = []
+for t in range(20, 60):
+    st.zero_()
+    env.step_walking_ptr(acts[t])
+    torch.cuda.synchronize()
+    acc.append(st.cpu().numpy().copy())
+env.lib.igw_debug_set_stamps(env.ctx, None)
+a = np.stack(acc)  # [launches, waves, 8]
+np.savez_compressed(out, stamps=a)
+t = a[:, :, :7].astype(np.float64)
+feat = a[:, :, 7]
+n_ch, n_rs, n_rt, max_m, n_brk = feat & 0xff, (feat >> 8) & 0xff, (feat >> 16) & 0xff, (feat >> 24) & 0xff, (feat >> 32) & 0xff
+life = t[:, :, 6] - t[:, :, 0]
+span = t[:, :, 6].max(1) - t[:, :, 0].min(1)
+names = ['loads', 'action + hit_test', 'physics', 'world_step tail', 'histogram update', 'rescan/finish/stores']
+d = np.diff(t, axis=2)
+print(f'lanes/env {gs}: {waves} waves, {a.shape[0]} launches; shader cycles')
+print(f'  first start -> last end: mean {span.mean():.0f}   start spread {np.mean(t[:, :, 0].max(1) - t[:, :, 0].min(1)):.0f}')
+print(f'  wave lifetime: mean {life.mean():.0f} p50 {np.percentile(life, 50):.0f} p90 {np.percentile(life, 90):.0f} '
+      f'p99 {np.percentile(life, 99):.0f} max(mean over launches) {life.max(1).mean():.0f}')
+for i, nm in enumerate(names):
+    print(f'  {nm:22s} mean {d[:, :, i].mean():8.0f}  p90 {np.percentile(d[:, :, i], 90):8.0f}  p99 {np.percentile(d[:, :, i], 99):8.0f}  max {d[:, :, i].max():8.0f}')
+print('  lifetime by work in the wave:')
+for label, m in (('no change, no reset', (n_ch == 0) & (n_rt == 0)), ('1 change', (n_ch == 1) & (n_rt == 0)),
+                 ('2 changes', (n_ch == 2) & (n_rt == 0)), ('3-4 changes', (n_ch >= 3) & (n_ch <= 4) & (n_rt == 0)),
+                 ('5+ changes', n_ch >= 5), ('rescan', n_rs > 0), ('reset', n_rt > 0), ('break', n_brk > 0),
+                 ('sub-steps 2', max_m == 2), ('sub-steps 4', max_m == 4), ('sub-steps 8+', max_m >= 8)):
+    if m.any():
+        print(f'    {label:20s} share {m.mean():6.3f}  lifetime mean {life[m].mean():8.0f}  p99 {np.percentile(life[m], 99):8.0f}'
+              f'  hist phase {d[:, :, 4][m].mean():7.0f}  last phase {d[:, :, 5][m].mean():7.0f}')
+# which waves end last
+last = life.argmax(1)
+print('  slowest wave per launch: changes', n_ch[np.arange(len(last)), last].tolist())
+print('                           resets ', n_rt[np.arange(len(last)), last].tolist())
+print('                           rescans', n_rs[np.arange(len(last)), last].tolist())
+print('                           m      ', max_m[np.arange(len(last)), last].tolist())
