@@ -29,6 +29,11 @@ class GridWorld:
         self.render_size, self.name = render_size, name
         self.max_steps, self.select_and_place, self.discretize = max_steps, select_and_place, discretize
         self.action_space_type = action_space
+        # kept with the caller's types: the reference's reward is `int * scale` (env.py:293-296), a Python int
+        # for the default right_placement_scale=1 and a float for wrong_placement_scale=0.1
+        self.right_placement_scale, self.wrong_placement_scale = right_placement_scale, wrong_placement_scale
+        self.size_reward = bool(size_reward)
+        self.right_placement = self.wrong_placement = 0
         self._vec = VecGridWorld(1, device=device, action_space=action_space, select_and_place=select_and_place,
                                  size_reward=size_reward, max_steps=max_steps,
                                  right_placement_scale=right_placement_scale, discretize=discretize,
@@ -125,10 +130,17 @@ class GridWorld:
         self._task.reset()
         self._upload_task()
         self._vec.reset(keep_size=keep_size)
-        return self._obs()
+        obs = self._obs()
+        self._counters = self._read_counters()
+        return obs
 
     def reset(self):
         return self._reset(keep_size=False)
+
+    def _read_counters(self):
+        """(max_int, prev_grid_size of the synthetic task, SizeReward.size): the integers the reward is made of."""
+        st = self._vec.task_state()
+        return int(st['max_int'][0]), int(st['prev_size'][0]), int(st['size'][0])
 
     def _obs(self):
         v = self._vec
@@ -167,7 +179,19 @@ class GridWorld:
             a = torch.tensor([int(action)], dtype=torch.int32)
         self._vec.step(a)
         obs = self._obs()
-        return obs, float(self._vec.reward[0].item()), bool(self._vec.done[0].item()), {}
+        # The reward as the reference's Python value: rebuilt from the device's integer counters with the
+        # reference's own expression, so -1 * 0.1 is the double -0.1 (the device's float32 copy is only a
+        # convenience for tensor consumers) and right * 1 stays an int.
+        mi0, sz0, size0 = self._counters
+        self._counters = mi1, sz1, size1 = self._read_counters()
+        self.right_placement, self.wrong_placement = right, wrong = mi1 - mi0, sz0 - sz1   # task.py:108-116
+        if right == 0:
+            reward = wrong * self.wrong_placement_scale                                       # env.py:293-296
+        else:
+            reward = right * self.right_placement_scale
+        if self.size_reward:   # SizeReward.step (env.py:325-331); GridWorld.wrong_placement stays 0 there (F6)
+            reward = (size1 - size0) + min(0 * 0.02, 0)
+        return obs, reward, bool(self._vec.done[0].item()), {}
 
     def render(self):
         raise ValueError('create env with render=True')

@@ -40,11 +40,12 @@ def test_facade_matches_reference(name, envs):
                 a = int(fx['actions'][e, t])
             obs, reward, done, info = env.step(a)
             assert done == bool(fx['done'][e, t]), (name, e, t)
-            assert np.float32(reward) == np.float32(fx['reward'][e, t]), (name, e, t)
+            # the reference's double, not a float32 rounding of it (-0.1, not -0.10000000149011612)
+            assert reward == fx['reward'][e, t] and isinstance(reward, (int, float)), (name, e, t, reward)
             assert np.array_equal(obs['inventory'], fx['inventory'][e, t])
-            if not fx['flying']:
-                assert np.array_equal(obs['agentPos'].view(np.uint32), fx['agentPos'][e, t].view(np.uint32))
-                assert obs['compass'][0] == fx['compass'][e, t]
+            # float32 observations bit-exact, flying included (A-fly contract)
+            assert np.array_equal(obs['agentPos'].view(np.uint32), fx['agentPos'][e, t].view(np.uint32)), (name, e, t)
+            assert obs['compass'][0] == fx['compass'][e, t]
 
 
 def test_facade_errors_and_spaces():
@@ -79,3 +80,71 @@ def test_task_generator_resamples_on_reset():
         seen.add(env.task.target_grid.tobytes())
         assert env.task.target_size == 5
     assert len(seen) > 1
+
+
+def test_target_in_obs():
+    """obs['target_grid'] is the task's target as int32 at reset and at every step (env.py:255-256, 297-298)."""
+    import gridworld_amd as G
+    fx = GR.load_fixture('s2_walk_cdm')
+    env = G.make('IGLUGridworldVector-v0', target_in_obs=True, **fx['kwargs'])
+    assert env.observation_space['target_grid'].shape == (9, 11, 11)
+    tgt = fx['targets'][3].astype(np.int32)
+    env.set_task(G.Task('', tgt, starting_grid=_sparse(fx['starts'][3])))
+    obs = env.reset()
+    assert obs['target_grid'].dtype == np.int32 and np.array_equal(obs['target_grid'], tgt)
+    for t in range(5):
+        obs, *_ = env.step(int(fx['actions'][3, t]))
+        assert np.array_equal(obs['target_grid'], tgt) and obs['target_grid'] is not tgt
+    plain = G.make('IGLUGridworldVector-v0', **fx['kwargs'])
+    plain.set_task(G.Task('', tgt, starting_grid=[]))
+    assert 'target_grid' not in plain.reset()
+
+
+def test_initialize_then_deinitialize_world():
+    """initialize_world overrides the starting grid and pose (fixture s5_init_pose was recorded that way);
+    deinitialize_world restores the task's own start and the default pose (env.py:177-193): after it the env
+    replays the plain fixture bit for bit."""
+    import gridworld_amd as G
+    fp, f1 = GR.load_fixture('s5_init_pose'), GR.load_fixture('s3_walk_rt20')
+    env = G.make('IGLUGridworldVector-v0', **fp['kwargs'])
+    e = 1
+    env.set_task(G.Task('', fp['targets'][e].astype(np.int32), starting_grid=[]))
+    with pytest.warns(UserWarning):
+        env.initialize_world(_sparse(fp['starts'][e]), [float(v) for v in fp['init_pose'][e]])
+    assert env.initial_position == tuple(float(v) for v in fp['init_pose'][e][:3])
+    env.reset()
+    for t in range(60):
+        obs, reward, done, _ = env.step(int(fp['actions'][e, t]))
+        assert np.array_equal(obs['agentPos'].view(np.uint32), fp['agentPos'][e, t].view(np.uint32)), t
+        assert reward == fp['reward'][e, t] and done == bool(fp['done'][e, t])
+    env.deinitialize_world()
+    assert env.initial_position == (0, 0, 0) and env.initial_rotation == (0, 0) and env._overwrite_starting_grid is None
+    env.set_task(G.Task('', f1['targets'][e].astype(np.int32), starting_grid=_sparse(f1['starts'][e])))
+    obs = env.reset()
+    assert np.array_equal(obs['grid'], f1['reset_grid'][e].reshape(9, 11, 11))
+    for t in range(80):
+        if f1['reset_before'][e, t]:
+            env.reset()
+        obs, reward, done, _ = env.step(int(f1['actions'][e, t]))
+        assert np.array_equal(obs['agentPos'].view(np.uint32), f1['agentPos'][e, t].view(np.uint32)), t
+        assert reward == f1['reward'][e, t] and done == bool(f1['done'][e, t])
+
+
+def test_actions_wrapper():
+    """Actions (wrappers.py:11-32): Discrete(17), index i -> Discrete(18) action i, `place` (17) dropped."""
+    import gridworld_amd as G
+    from gridworld_amd.wrappers import Actions
+    fx = GR.load_fixture('s1_walk_dummy')
+    env = Actions(G.make('IGLUGridworldVector-v0', **fx['kwargs']))
+    assert env.action_space.n == 17 and env.action_map == list(range(17))
+    env.set_task(G.Task('', fx['targets'][0].astype(np.int32), starting_grid=[], **fx['task_kwargs']))   # pass-through attribute
+    env.reset()
+    acts = [int(a) for a in fx['actions'][0] if a != 17][:40]
+    ref = G.make('IGLUGridworldVector-v0', **fx['kwargs'])
+    ref.set_task(G.Task('', fx['targets'][0].astype(np.int32), starting_grid=[], **fx['task_kwargs']))
+    ref.reset()
+    for a in acts:
+        o1, r1, d1, _ = env.step(a)
+        o2, r2, d2, _ = ref.step(a)
+        assert r1 == r2 and d1 == d2 and np.array_equal(o1['agentPos'], o2['agentPos'])
+    assert env.unwrapped is env.env and env.max_steps == ref.max_steps
