@@ -14,7 +14,7 @@ GRID_STRIDE = 1104
 CELLS = 1089
 AGENT_BYTES = 64
 TASK_META_BYTES = 128
-OCC_WORDS = 36
+OCC_WORDS = 48
 HIST_ROW = 512
 STAT_STRIPES = 64
 STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS = 0, 1, 2, 3

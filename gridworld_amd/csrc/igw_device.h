@@ -3,10 +3,10 @@
 // Execution model: GS lanes of a wavefront (GS = 64, 32, ..., 1; a "group") own one env.
 // The serial double-precision physics chain is evaluated redundantly by every lane of the
 // group (no broadcast needed, the wave issues the instruction anyway); the lanes of a group
-// split the 40 ray-march samples of hit_test.  The per-step working set of an env is its
-// 144-byte occupancy bitmap, staged in LDS; the int8 colour grid stays in HBM and is touched
-// only where a colour matters.  Row-sized or rare work (histogram updates, rescans, resets,
-// Task.__init__) is done by the whole wave, coalesced.
+// split the ray march of hit_test (by coordinate in 4-lane groups, by sample otherwise).  The
+// per-step working set of an env is its 192-byte padded occupancy bitmap, staged in LDS; the int8
+// colour grid stays in HBM and is touched only where a colour matters.  Row-sized or rare work
+// (histogram updates, resets, Task.__init__) is done by the whole wave, coalesced.
 // All arithmetic is IEEE binary64 with one rounding per operation, in the reference's
 // operation order (compile with -ffp-contract=off, never fast-math).
 #pragma once
@@ -33,10 +33,24 @@ constexpr int LEVEL = 121;           // cells per y level
 constexpr int HIST_BINS = 4 * 121;
 constexpr int HIST_WORDS = HIST_BINS / 2;  // 242
 constexpr int HIST_PAD = 256;
-// occupancy bitmap of the 1089 cells (bit = cell index): the per-step working set of the physics
-constexpr int OCC_WORDS = IGW_OCC_WORDS;  // 36 dwords = 144 B per env in HBM
-constexpr int OCC_PITCH = 37;             // LDS pitch (odd => conflict-free when one lane owns one env)
+// Occupancy bitmap, the per-step working set of the physics.  HBM: OCC_WORDS dwords per env, one bit per
+// cell of the 9 x 13 x 13 box that pads every y level of the build zone with one always-empty cell on each
+// side in x and z: bit = (y+1)*169 + (x+6)*13 + (z+6).  LDS: the same words behind a constant prefix that
+// holds two empty levels (y <= -3) and the ground plane (y = -2, all ones), followed by a constant empty
+// level (y >= 8), so that `key in world` for ANY integer cell is one bit test at
+//   idx = L*169 + xp*13 + zp + OCC_IDX0,  L = clamp(y,-4,8)+4, xp = clamp(x,-6,6)+6, zp = clamp(z,-6,6)+6
+// with no range checks: clamping sends everything outside the zone to a padding cell or a constant level,
+// and all three clamps are [0, 12] after their (even) offsets, i.e. one v_med3_i32 each.
+// (The ground plane spans |x|,|z| <= 18; agents stay within |x|,|z| <= 10 -- poses are validated -- and a
+// ray is 8 long, so every sample at y = -2 is on it.)
+constexpr int OCC_WORDS = IGW_OCC_WORDS;  // 48 dwords = 192 B per env in HBM
+constexpr int OCC_LAYER = 169;            // 13 x 13 bits per level
+constexpr int OCC_VAR0 = 16;              // LDS word of HBM word 0 (16-byte aligned)
+constexpr int OCC_IDX0 = 32 * OCC_VAR0 - 3 * OCC_LAYER;  // 5: level L = 3 (y = -1) starts at LDS word OCC_VAR0
+constexpr int OCC_PITCH = 72;             // LDS words per env: 16 constant + 48 variable + 8 constant zero
 constexpr int HIST_ROW = IGW_HIST_ROW;    // persistent per-env vote histogram: 512 x u16 (484 used)
+static_assert(OCC_IDX0 >= 0 && OCC_IDX0 + 12 * OCC_LAYER + 12 * 13 + 12 < 32 * OCC_PITCH, "LDS occupancy row too short");
+static_assert(9 * OCC_LAYER <= 32 * OCC_WORDS, "HBM occupancy row too short");
 
 // gridworld/utils.py:9-24 and core/world.py:9
 constexpr double WALKING_SPEED = 5.0;
@@ -100,8 +114,8 @@ struct KParams {
 // Fixed cross-lane patterns inside a quad (4 consecutive lanes) as DPP moves: one VALU instruction instead
 // of a trip through the LDS crossbar (ds_bpermute).  CTRL = quad_perm: bits [2i+1:2i] = source lane of lane i.
 template <int CTRL>
-__device__ inline int dpp_quad(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+__device__ inline int dpp_quad(int v) {  // every quad_perm source lane exists, so there is no `old` value to keep
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ inline double dpp_quad(double v) {
@@ -246,22 +260,27 @@ __device__ inline bool build_zone_i(int x, int y, int z) {
 }
 __device__ inline int cell_of(int x, int y, int z) { return (y + 1) * LEVEL + (x + 5) * 11 + (z + 5); }
 
-// `key in world` answered from the env's occupancy bitmap in LDS plus the fixed ground plane
-// (World._initialize, core/world.py:60-71: y=-2, |x|,|z|<=18, WHITE(-1) over the build zone else GREY(0)).
-// Colours live in the int8 grid row in HBM and are only fetched for the one block a break hits.
+// bit of a build-zone cell in the HBM occupancy row / of any integer cell in the LDS row
+__device__ inline int occ_bit_hbm(int x, int y, int z) { return (y + 1) * OCC_LAYER + (x + 6) * 13 + (z + 6); }
+__device__ inline int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }  // one v_med3_i32
+__device__ inline int occ_idx(int x, int y, int z) {
+    return (clampi(y, -4, 8) + 4) * OCC_LAYER + (clampi(x, -6, 6) + 6) * 13 + (clampi(z, -6, 6) + 6) + OCC_IDX0;
+}
 __device__ inline bool occ_test(const uint32_t* occ_s, int idx) { return (occ_s[idx >> 5] >> (idx & 31)) & 1u; }
 
-__device__ inline bool world_has(const uint32_t* occ_s, int x, int y, int z) {
-    if (y == -2) return x >= -18 && x <= 18 && z >= -18 && z <= 18;
-    if (!build_zone_i(x, y, z)) return false;
-    return occ_test(occ_s, cell_of(x, y, z));
-}
-// same without control flow (the bitmap word is always read, index clamped to 0 outside the zone): used
-// where the lanes of a wave disagree on the outcome anyway and branches only cost exec-mask bookkeeping
-__device__ inline bool world_has_nobranch(const uint32_t* occ_s, int x, int y, int z) {
-    const bool ground = y == -2 && (unsigned)(x + 18) <= 36u && (unsigned)(z + 18) <= 36u;
-    const bool in = build_zone_i(x, y, z);
-    return (int)ground | ((int)in & (int)occ_test(occ_s, in ? cell_of(x, y, z) : 0));
+// `key in world` (World.world dict membership, core/world.py:60-71 ground plane + placed blocks): one LDS
+// bit test, no control flow.  Colours live in the int8 grid row in HBM and are only fetched for the one
+// block a break hits.
+__device__ inline bool world_has(const uint32_t* occ_s, int x, int y, int z) { return occ_test(occ_s, occ_idx(x, y, z)); }
+
+// constant words of one env's LDS occupancy row (see OCC_IDX0): words 0..15 = two empty levels + the ground
+// plane, words 64..71 = zero (the empty level above the zone reaches word 68)
+__host__ __device__ constexpr uint32_t occ_const_word(int w) {
+    constexpr int g0 = OCC_IDX0 + 2 * OCC_LAYER, g1 = OCC_IDX0 + 3 * OCC_LAYER;  // ground plane bits [g0, g1)
+    if (w >= OCC_VAR0) return 0u;
+    const int lo = g0 - 32 * w > 0 ? g0 - 32 * w : 0, hi = g1 - 32 * w < 32 ? g1 - 32 * w : 32;
+    if (hi <= lo) return 0u;
+    return (hi - lo == 32) ? 0xffffffffu : (((1u << (hi - lo)) - 1u) << lo);
 }
 
 // ---------------------------------------------------------------- trig front-end
@@ -307,34 +326,19 @@ __device__ inline double div5(double x) {
 
 // ---------------------------------------------------------------- collide (core/world.py:264-310)
 
-// Neighbourhood prober for collide: the 12 probes are np + small offsets, so the range checks of
-// world_has (build zone per axis, ground plane y == -2 inside |x|,|z| <= 18) are hoisted per axis value
-// and a probe is one add + one LDS bit test.
+// Neighbourhood prober for collide: the 12 probes are np + small offsets; each is one clamped index and
+// one LDS bit test (occ_idx).
 struct Probe {
     const uint32_t* occ_s;
-    int base;            // cell_of(nx, ny, nz), may be out of range; only used when the axes are valid
     int nx, ny, nz;
-    __device__ bool at(int dx, int dy, int dz) const {
-        const int x = nx + dx, y = ny + dy, z = nz + dz;
-        if (y == -2) return x >= -18 && x <= 18 && z >= -18 && z <= 18;
-        const bool in = (unsigned)(x + 5) <= 10u && (unsigned)(z + 5) <= 10u && (unsigned)(y + 1) <= 8u;
-        return in && occ_test(occ_s, base + dy * LEVEL + dx * 11 + dz);
-    }
-    // same without control flow: the bitmap word is always read (index clamped to 0 when out of range)
-    __device__ bool at_nobranch(int dx, int dy, int dz) const {
-        const int x = nx + dx, y = ny + dy, z = nz + dz;
-        const bool ground = y == -2 && (unsigned)(x + 18) <= 36u && (unsigned)(z + 18) <= 36u;
-        const bool in = (unsigned)(x + 5) <= 10u && (unsigned)(z + 5) <= 10u && (unsigned)(y + 1) <= 8u;
-        const int idx = in ? base + dy * LEVEL + dx * 11 + dz : 0;
-        return (int)ground | ((int)in & (int)occ_test(occ_s, idx));
-    }
+    __device__ bool at(int dx, int dy, int dz) const { return world_has(occ_s, nx + dx, ny + dy, nz + dz); }
 };
 
 // Six faces in the reference order; a face only probes when its overlap test passes.  (Issuing all 12
 // probes up front -- they depend only on np -- was measured slower at every group size.)
 __device__ inline void collide(Env& e, const uint32_t* occ_s, double& px, double& py, double& pz) {
     const int nx = rint_i32(px), ny = rint_i32(py), nz = rint_i32(pz);
-    const Probe w{occ_s, cell_of(nx, ny, nz), nx, ny, nz};
+    const Probe w{occ_s, nx, ny, nz};
     double d;
     d = (py - (double)ny) * 1.0;  // face (0, 1, 0): heights dy = 0, 1 probe (nx, ny - dy + 1, nz)
     if (!(d < PAD)) {
@@ -372,27 +376,29 @@ __device__ inline void collide(Env& e, const uint32_t* occ_s, double& px, double
 // the faces in the order y+, y-, x-, x+, z+, z-; a face reads and writes only its own coordinate and its
 // probes depend only on np, so the axes are independent and only the two faces of one axis are ordered.
 // Lane (gl & 3) = 0 / 3 takes y, 1 takes x, 2 takes z, with exactly the reference's arithmetic; the three
-// results (and dy, which only the y faces clear) are then exchanged inside the group.
+// results (and dy, which only the y faces clear) are then exchanged inside the group.  Everything is
+// predicated, not branched: the lanes of a wave disagree on almost every test.
 template <int GS>
 __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* occ_s, double& px, double& py,
                                      double& pz) {
     static_assert(GS >= 4, "needs three lanes per env");
     const int nx = rint_i32(px), ny = rint_i32(py), nz = rint_i32(pz);
-    const Probe w{occ_s, cell_of(nx, ny, nz), nx, ny, nz};
     const int a = G.gl & 3;
     const bool ax = a == 1, az = a == 2;
     const int ux = ax ? 1 : 0, uz = az ? 1 : 0, uy = (ax || az) ? 0 : 1;
     double pa = ax ? px : az ? pz : py;
     const double na = (double)(ax ? nx : az ? nz : ny);
     double vy = e.vy;
-    const int i1 = ax ? -1 : 1;          // first face of the axis: (0,1,0), (-1,0,0), (0,0,1)
-    const double f1 = ax ? -1.0 : 1.0;
-    // predicated instead of branched: lanes of a wave disagree on almost every one of these tests, so the
-    // branches bought nothing and cost exec-mask bookkeeping; the selects keep the arithmetic identical
-    const int i2 = -i1;                  // second face: (0,-1,0), (1,0,0), (0,0,-1)
-    const double f2 = ax ? 1.0 : -1.0;
-    const bool b1 = (int)w.at_nobranch(ux * i1, uy * i1, uz * i1) | (int)w.at_nobranch(ux * i1, uy * i1 - 1, uz * i1);
-    const bool b2 = (int)w.at_nobranch(ux * i2, uy * i2, uz * i2) | (int)w.at_nobranch(ux * i2, uy * i2 - 1, uz * i2);
+    const int i1 = ax ? -1 : 1;          // first face of the axis: (0,1,0), (-1,0,0), (0,0,1); the second is -i1
+    const double f1 = ax ? -1.0 : 1.0, f2 = ax ? 1.0 : -1.0;
+    // the four probe cells differ from np only along this lane's axis (and one level down): the x and z terms
+    // of the index take two values each, the level term four
+    const int xa = (clampi(nx + ux * i1, -6, 6) + 6) * 13, xb = (clampi(nx - ux * i1, -6, 6) + 6) * 13;
+    const int za = clampi(nz + uz * i1, -6, 6) + 6 + OCC_IDX0, zb = clampi(nz - uz * i1, -6, 6) + 6 + OCC_IDX0;
+    const int ya0 = (clampi(ny + uy * i1, -4, 8) + 4) * OCC_LAYER, ya1 = (clampi(ny + uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
+    const int yb0 = (clampi(ny - uy * i1, -4, 8) + 4) * OCC_LAYER, yb1 = (clampi(ny - uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
+    const bool b1 = (int)occ_test(occ_s, ya0 + xa + za) | (int)occ_test(occ_s, ya1 + xa + za);
+    const bool b2 = (int)occ_test(occ_s, yb0 + xb + zb) | (int)occ_test(occ_s, yb1 + xb + zb);
     double d = (pa - na) * f1;
     const bool h1 = !(d < PAD) && b1;
     pa = h1 ? pa - (d - PAD) * f1 : pa;
@@ -410,12 +416,33 @@ __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* o
 
 struct Hit {
     bool hit, have_prev;
-    int bx, by, bz;  // the block that was hit (ground when by == -2)
-    int px, py, pz;  // `previous`: the last empty cell in front of it
+    int bx, by, bz;  // the block that was hit (ground when by == -2); outside the zone: clamped (see occ_idx)
+    int px, py, pz;  // `previous`: the last empty cell in front of it (clamped likewise)
 };
 
+// A sample's cell as the three clamped, offset coordinates of occ_idx packed in one word:
+//   key = xp | L << 8 | zp << 16,  xp = clamp(x,-6,6)+6, L = clamp(y,-4,8)+4, zp = clamp(z,-6,6)+6.
+// The offsets are EVEN so they can ride in the rounding constant: x + (1.5 * 2^52 + 6) rounds to the same
+// integer (ties to even keep their parity) and leaves normalize(x) + 6 in the low dword (rint_i32).
+// Clamped keys answer everything hit_test is asked: cells outside the zone are only ever "in world" on the
+// ground plane, whose first sample always differs from its predecessor in L; `previous` matters only inside
+// the zone, where nothing is clamped (the clamp range strictly contains the zone).
+constexpr double RINT_MAGIC = 0x1.8p52;
+__device__ inline int key_idx(int key) {  // occ_idx of a packed key: L*169 + xp*13 + zp + OCC_IDX0, one v_dot4_u32_u8
+    return (int)__builtin_amdgcn_udot4((unsigned)key, 0x0001A90Du, (unsigned)OCC_IDX0, false);
+}
+__device__ inline int key_of(double x, double y, double z) {
+    const int xp = clampi(__double2loint(x + (RINT_MAGIC + 6.0)), 0, 12);
+    const int l1 = clampi(__double2loint(y + (RINT_MAGIC + 4.0)), 0, 12);
+    const int zp = clampi(__double2loint(z + (RINT_MAGIC + 6.0)), 0, 12);
+    return xp | (l1 << 8) | (zp << 16);
+}
+__device__ inline void key_unpack(int key, int& x, int& y, int& z) {
+    x = (key & 0xff) - 6; y = ((key >> 8) & 0xff) - 4; z = ((key >> 16) & 0xff) - 6;
+}
+
 // Sample k is position + k sequential additions of vector/5 (the reference's recurrence, so the
-// rounding of every partial sum is reproduced); the 40 samples are split over the lanes of the group.
+// rounding of every partial sum is reproduced).
 template <int GS>
 __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x, double y, double z,
                                double vx, double vy, double vz) {
@@ -427,70 +454,99 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
     h.px = h.py = h.pz = 0;
     if constexpr (GS == 1) {
         // one lane per env: the reference loop as is; stop when every active lane has its answer
-        int qx = 0, qy = 0, qz = 0;
+        int q = 0, bk = 0, pk = 0;
         for (int s = 0; s < SAMPLES; s++) {
-            const int kx = rint_i32(x), ky = rint_i32(y), kz = rint_i32(z);
-            const bool differs = (s == 0) || kx != qx || ky != qy || kz != qz;
-            if (!h.hit && differs && world_has(occ_s, kx, ky, kz)) {
+            const int k = key_of(x, y, z);
+            if (!h.hit && ((s == 0) || k != q) && occ_test(occ_s, key_idx(k))) {
                 h.hit = true;
                 h.have_prev = s != 0;
-                h.bx = kx; h.by = ky; h.bz = kz;
-                h.px = qx; h.py = qy; h.pz = qz;
+                bk = k; pk = q;
             }
             if (!__any(!h.hit)) break;
-            qx = kx; qy = ky; qz = kz;
+            q = k;
             x = x + sx; y = y + sy; z = z + sz;
+        }
+        key_unpack(bk, h.bx, h.by, h.bz);
+        key_unpack(pk, h.px, h.py, h.pz);
+        return h;
+    } else if constexpr (GS == 4) {
+        // Coordinate split: lane 0 / 1 / 2 of the group carries the x / y / z recurrence alone (39 sequential
+        // adds instead of 117 per lane) and rounds + clamps its coordinate of all 40 samples; four samples at
+        // a time travel as the four bytes of one word per coordinate, are broadcast inside the quad, and lane
+        // j assembles the key of sample 4r + j from byte j of the three words and tests it.
+        constexpr int ROUNDS = SAMPLES / 4;
+        const int a = G.gl & 3;
+        double c = a == 0 ? x : a == 1 ? y : z;
+        const double sc = a == 0 ? sx : a == 1 ? sy : sz;
+        const double magic = RINT_MAGIC + (a == 1 ? 4.0 : 6.0);
+        // byte selectors (v_perm_b32: 0-3 = bytes of the second source, 4-7 = bytes of the first, 0x0c = zero)
+        const unsigned sel_xy = 0x0c0c0000u | (unsigned)G.gl | ((4u + (unsigned)G.gl) << 8);
+        const unsigned sel_z = 0x0c000100u | ((4u + (unsigned)G.gl) << 16);
+        int key[ROUNDS];
+        uint32_t word[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            int w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                w |= clampi(__double2loint(c + magic), 0, 12) << (8 * j);
+                if (r * 4 + j + 1 < SAMPLES) c = c + sc;
+            }
+            const unsigned wx = (unsigned)dpp_quad<QUAD_BCAST0>(w), wy = (unsigned)dpp_quad<QUAD_BCAST1>(w),
+                           wz = (unsigned)dpp_quad<QUAD_BCAST2>(w);
+            // byte gl of wx, wy, wz -> bytes 0, 1, 2 of the key
+            key[r] = (int)__builtin_amdgcn_perm(wz, __builtin_amdgcn_perm(wy, wx, sel_xy), sel_z);
+            word[r] = occ_s[key_idx(key[r]) >> 5];  // all probes are issued before the first is consumed
+        }
+        // `key != previous and key in world`, first sample wins: every lane scans its own samples (previous =
+        // the neighbouring lane's key of the same round, or lane 3's key of the round before); sample number
+        // and key share one word, so one group minimum yields the earliest candidate and its key.
+        int best = SAMPLES << 24, bprev = SAMPLES << 24;
+        const int gtag = G.gl << 24;
+#pragma unroll
+        for (int r = ROUNDS - 1; r >= 0; r--) {  // descending, so the earliest candidate wins
+            // previous sample's key: lane j-1's key of this round, for lane 0 lane 3's key of the round before
+            // (lane 3 offers that one, then one rotation of the quad delivers both)
+            const int offer = (r > 0 && G.gl == 3) ? key[r - 1] : key[r];
+            const int q = dpp_quad<0x93>(offer);  // quad_perm [3, 0, 1, 2]
+            const bool inw = (word[r] >> (key_idx(key[r]) & 31)) & 1u;
+            const bool cand = ((r == 0 && G.gl == 0) || key[r] != q) && inw;
+            const int tag = gtag | ((r * 4) << 24);  // sample number 4r + j above the 24 key bits
+            if (cand) { best = tag | key[r]; bprev = tag | q; }
+        }
+        best = G.group_min(best);
+        bprev = G.group_min(bprev);
+        if ((best >> 24) < SAMPLES) {
+            h.hit = true;
+            h.have_prev = (best >> 24) != 0;
+            key_unpack(best & 0xffffff, h.bx, h.by, h.bz);
+            key_unpack(bprev & 0xffffff, h.px, h.py, h.pz);
         }
         return h;
     } else {
-        if constexpr (GS <= 2) {
-            // Lane j of the group owns the contiguous samples j*C .. j*C+C-1.  It first walks to its chunk
-            // (j*C sequential adds -- the reference's recurrence, nothing can be skipped), then evaluates its C
-            // samples; `previous` is lane-local except for the chunk's first sample (one shuffle), and the
-            // first `key != previous and key in world` of the whole ray is a per-lane scan + one group minimum.
-            constexpr int C = (SAMPLES + GS - 1) / GS;
-            const int lead = G.gl * C;  // samples in front of this lane's chunk
+        // Sample split.  Groups of 2: lane j owns the contiguous samples j*C .. j*C+C-1 (it first walks to its
+        // chunk -- the reference's recurrence, nothing can be skipped).  Wider groups: lane j owns samples
+        // j, j+GS, ... (every round after the first advances all lanes by GS unmasked adds).  `previous` of a
+        // lane's sample is the neighbouring sample's key (one shuffle); the first `key != previous and key in
+        // world` of the whole ray is a per-lane scan plus one group minimum.
+        constexpr bool CHUNKED = GS == 2;
+        constexpr int C = (SAMPLES + GS - 1) / GS;  // samples per lane (chunked) = rounds (strided)
+        int key[C];
+        bool inw[C];
+        if constexpr (CHUNKED) {
+            const int lead = G.gl * C;
             for (int i = 0; i < (GS - 1) * C && i < SAMPLES - 1; i++) {
                 if (i < lead) { x = x + sx; y = y + sy; z = z + sz; }
             }
-            int key[C];  // packed (kx+128) | (ky+128) << 8 | (kz+128) << 16
-            bool inw[C];
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < C; k++) {
-                const int kx = rint_i32(x), ky = rint_i32(y), kz = rint_i32(z);
-                key[k] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
-                inw[k] = world_has_nobranch(occ_s, kx, ky, kz);
+                key[k] = key_of(x, y, z);
+                inw[k] = occ_test(occ_s, key_idx(key[k]));
                 if (k + 1 < C) { x = x + sx; y = y + sy; z = z + sz; }
             }
-            int q = G.shfl_up1(key[C - 1]);  // last key of the previous lane's chunk = `previous` of our first sample
-            int first = SAMPLES, fkey = 0, fprev = 0;
-    #pragma unroll
-            for (int k = C - 1; k >= 0; k--) {  // descending, so the earliest candidate wins
-                const int s = lead + k;
-                const int prev = (k == 0) ? q : key[k - 1];
-                const bool cand = s < SAMPLES && ((s == 0) || key[k] != prev) && inw[k];
-                if (cand) { first = s; fkey = key[k]; fprev = prev; }
-            }
-            int best = first;
-    #pragma unroll
-            for (int o = GS / 2; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, GS));
-            if (best < SAMPLES) {
-                const int owner = best / C;
-                const int bk = G.bcast(fkey, owner), pk = G.bcast(fprev, owner);
-                h.hit = true;
-                h.have_prev = best != 0;
-                h.bx = (bk & 0xff) - 128; h.by = ((bk >> 8) & 0xff) - 128; h.bz = ((bk >> 16) & 0xff) - 128;
-                h.px = (pk & 0xff) - 128; h.py = ((pk >> 8) & 0xff) - 128; h.pz = ((pk >> 16) & 0xff) - 128;
-            }
         } else {
-            // Strided mapping (lane j owns samples j, j+GS, ...): every round after the first advances all
-            // lanes by GS unmasked adds, which is cheaper than the chunked walk once groups are 4+ wide.
-            constexpr int ROUNDS = (SAMPLES + GS - 1) / GS;
-            // pass 1: every lane walks to its samples (pure ALU) and issues all its membership probes
-            int key[ROUNDS];  // packed (kx+128) | (ky+128) << 8 | (kz+128) << 16
-            bool inw[ROUNDS];
-    #pragma unroll
-            for (int r = 0; r < ROUNDS; r++) {
+#pragma unroll
+            for (int r = 0; r < C; r++) {
                 int nadd = (r == 0) ? G.gl : GS;
                 if (GS == 64) nadd = min(nadd, SAMPLES - 1);
                 const int bound = (r == 0) ? min(GS - 1, SAMPLES - 1) : GS;
@@ -499,37 +555,40 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
                         if (i < nadd) { x = x + sx; y = y + sy; z = z + sz; }
                     }
                 } else {
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < bound; i++) { x = x + sx; y = y + sy; z = z + sz; }
                 }
-                const int kx = rint_i32(x), ky = rint_i32(y), kz = rint_i32(z);
-                key[r] = (kx + 128) | ((ky + 128) << 8) | ((kz + 128) << 16);
-                inw[r] = world_has_nobranch(occ_s, kx, ky, kz);
+                key[r] = key_of(x, y, z);
+                inw[r] = occ_test(occ_s, key_idx(key[r]));
             }
-            // pass 2: `key != previous and key in world`, first sample wins.  Every lane scans its own samples
-            // (previous = the neighbouring lane's key of the same round, or the last lane's key of the round
-            // before), then one group minimum picks the earliest candidate: no ballot / branch per round.
-            int first = SAMPLES, fkey = 0, fprev = 0;
+        }
+        int first = SAMPLES, fkey = 0, fprev = 0;
 #pragma unroll
-            for (int r = ROUNDS - 1; r >= 0; r--) {  // descending, so the earliest candidate wins
-                const int s = r * GS + G.gl;
-                int q = G.shfl_up1(key[r]);
-                if (r > 0) {
-                    const int wrap = G.bcast_last(key[r - 1]);
-                    if (G.gl == 0) q = wrap;
+        for (int k = C - 1; k >= 0; k--) {  // descending, so the earliest candidate wins
+            int s, prev;
+            if constexpr (CHUNKED) {
+                s = G.gl * C + k;
+                const int q = G.shfl_up1(key[C - 1]);  // last key of the previous lane's chunk
+                prev = (k == 0) ? q : key[k - 1];
+            } else {
+                s = k * GS + G.gl;
+                prev = G.shfl_up1(key[k]);
+                if (k > 0) {
+                    const int wrap = G.bcast_last(key[k - 1]);
+                    if (G.gl == 0) prev = wrap;
                 }
-                const bool cand = s < SAMPLES && ((s == 0) || key[r] != q) && inw[r];
-                if (cand) { first = s; fkey = key[r]; fprev = q; }
             }
-            const int best = G.group_min(first);
-            if (best < SAMPLES) {
-                const int owner = best % GS;
-                const int bk = G.bcast(fkey, owner), pk = G.bcast(fprev, owner);
-                h.hit = true;
-                h.have_prev = best != 0;
-                h.bx = (bk & 0xff) - 128; h.by = ((bk >> 8) & 0xff) - 128; h.bz = ((bk >> 16) & 0xff) - 128;
-                h.px = (pk & 0xff) - 128; h.py = ((pk >> 8) & 0xff) - 128; h.pz = ((pk >> 16) & 0xff) - 128;
-            }
+            const bool cand = s < SAMPLES && ((s == 0) || key[k] != prev) && inw[k];
+            if (cand) { first = s; fkey = key[k]; fprev = prev; }
+        }
+        const int best = G.group_min(first);
+        if (best < SAMPLES) {
+            const int owner = CHUNKED ? best / C : best % GS;
+            const int bk = G.bcast(fkey, owner), pk = G.bcast(fprev, owner);
+            h.hit = true;
+            h.have_prev = best != 0;
+            key_unpack(bk, h.bx, h.by, h.bz);
+            key_unpack(pk, h.px, h.py, h.pz);
         }
         return h;
     }

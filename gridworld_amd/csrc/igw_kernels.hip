@@ -83,7 +83,8 @@ __device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_si
 }
 
 // whole-wave copy of the starting grid and its occupancy bitmap into one env's rows
-// (env.py:234-238: world := starting grid); occ_s may be nullptr when the kernel ends right after
+// (env.py:234-238: world := starting grid); occ_s (the env's LDS occupancy row) may be nullptr when the
+// kernel ends right after
 __device__ inline void reset_rows_wave(const KParams& p, int env, int task, bool has_start, uint32_t* occ_s) {
     const int lane = __lane_id();
     uint4* dg = reinterpret_cast<uint4*>(p.grid + (size_t)env * STRIDE);
@@ -92,7 +93,7 @@ __device__ inline void reset_rows_wave(const KParams& p, int env, int task, bool
     if (lane < OCC_WORDS) {
         const uint32_t v = has_start ? p.task_start_occ[(size_t)task * OCC_WORDS + lane] : 0u;
         p.occ[(size_t)env * OCC_WORDS + lane] = v;
-        if (occ_s) occ_s[lane] = v;
+        if (occ_s) occ_s[OCC_VAR0 + lane] = v;
     }
     // grid == start  =>  synthetic grid empty  =>  no votes
     reinterpret_cast<uint4*>(p.hist + (size_t)env * HIST_ROW)[lane] = make_uint4(0, 0, 0, 0);
@@ -119,19 +120,26 @@ __device__ inline void write_step_obs(const KParams& p, int env, const Env& e) {
 }
 
 struct CellChange {
-    int idx;  // -1: grid unchanged this step
+    int idx;  // dense cell index; -1: grid unchanged this step
+    int bit;  // the cell's bit in the HBM occupancy row
     int old_val, new_val;
 };
 
-// World.step (core/world.py:434-456) after action parsing, for one env; every lane of the group runs
-// it with identical inputs, hit_test splits its samples over the lanes.
+struct Motion {  // get_motion_vector (core/world.py:163-201): constant over the sub-steps of one step
+    double x, y, z;
+};
+
+// World.step (core/world.py:434-456) after action parsing, first half: movement, camera, place / break.
+// Every lane of the group runs it with identical inputs, hit_test splits its work over the lanes.  For a
+// break, ch.old_val is the pending colour load of the block that was hit: nothing here waits for it
+// (finish_break consumes it after the physics).
 template <int GS, int MODE>
-__device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
-                                        const int8_t* grid_g, const TrigCtx& trig, double s0, double s1, double dy,
-                                        int inventory, double cam0, double cam1, bool remove, bool add) {
+__device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
+                                       const int8_t* grid_g, const TrigCtx& trig, double s0, double s1, double dy,
+                                       int inventory, double cam0, double cam1, bool remove, bool add, Motion& mv) {
     constexpr bool FLY = MODE == MODE_FLY;
     CellChange ch;
-    ch.idx = -1; ch.old_val = 0; ch.new_val = 0;
+    ch.idx = -1; ch.bit = 0; ch.old_val = 0; ch.new_val = 0;
     if (p.select_and_place && inventory != 0) { add = true; remove = false; }  // :444-446
     // movement, :344-356
     if (dy != 0.0 && e.vy == 0.0) e.vy = JUMP_SPEED * dy;
@@ -173,6 +181,21 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
         if (want_sight) sincos_deg(trig, e.yaw - 90.0, sy, cy);
         if (strafing) sincos_deg(trig, e.yaw + strafe_deg, sx, cx);
     }
+    // get_motion_vector, :163-201 (rotation and strafe are constant over the sub-steps)
+    mv.x = 0.0; mv.y = 0.0; mv.z = 0.0;
+    if (strafing) {
+        if (FLY) {
+            double mm = cp;
+            mv.y = sp;
+            if (s1 != 0.0) { mv.y = 0.0; mm = 1.0; }
+            if (s0 > 0.0) mv.y *= -1.0;
+            mv.x = cx * mm;
+            mv.z = sx * mm;
+        } else {
+            mv.x = cx;
+            mv.z = sx;
+        }
+    }
     // place_or_remove_block, :312-332
     if (want_sight) {
         // m = cos(radians(y)); dy = sin(radians(y)); dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
@@ -188,6 +211,7 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
                                          ((by <= y && y <= by + 1.0) || (by <= (y + 1.0) && (y + 1.0) <= by + 1.0));
                     if (!overlap) {
                         ch.idx = cell_of(h.px, h.py, h.pz);
+                        ch.bit = occ_bit_hbm(h.px, h.py, h.pz);
                         ch.old_val = 0;  // `previous` is never occupied
                         ch.new_val = e.active;
                         e.inv = inv_add(e.inv, e.active - 1, -1);
@@ -199,96 +223,91 @@ __device__ inline CellChange world_step(const Grp<GS>& G, const KParams& p, Env&
             const int cell = cell_of(h.bx, h.by, h.bz);
             // colour of the block: the one int8 the physics ever needs (L1-bypassing load: a fused
             // rollout may have written this row earlier in the same launch)
-            const int texture = __hip_atomic_load(grid_g + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ch.old_val = __hip_atomic_load(grid_g + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ch.idx = cell;
-            ch.old_val = texture;
+            ch.bit = occ_bit_hbm(h.bx, h.by, h.bz);
             ch.new_val = 0;
-            if (texture >= 1 && texture <= 6) e.inv = inv_add(e.inv, texture - 1, 1);
         }
         if (ch.idx >= 0) {
             wave_sync();
             if (G.gl == 0) {
-                const uint32_t bit = 1u << (ch.idx & 31);
-                uint32_t w = occ_s[ch.idx >> 5];
+                const int li = ch.bit + 32 * OCC_VAR0;  // the HBM row sits behind the constant prefix in LDS
+                const uint32_t bit = 1u << (li & 31);
+                uint32_t w = occ_s[li >> 5];
                 w = ch.new_val ? (w | bit) : (w & ~bit);
-                occ_s[ch.idx >> 5] = w;
+                occ_s[li >> 5] = w;
             }
             wave_sync();
         }
     }
-    stamp(p, 2);
-    // update(dt = 1/20), :203-220
-    {
-        const int m = e.tis;
-        const double dt = m == 2 ? 0.05 / 2 : m == 4 ? 0.05 / 4 : m == 8 ? 0.05 / 8 : 0.05 / 12;
-        // get_motion_vector, :163-201 (rotation and strafe are constant over the sub-steps)
-        double mvx = 0.0, mvy = 0.0, mvz = 0.0;
-        if (strafing) {
-            if (FLY) {
-                double mm = cp;
-                mvy = sp;
-                if (s1 != 0.0) { mvy = 0.0; mm = 1.0; }
-                if (s0 > 0.0) mvy *= -1.0;
-                mvx = cx * mm;
-                mvz = sx * mm;
-            } else {
-                mvy = 0.0;
-                mvx = cx;
-                mvz = sx;
-            }
-        }
-        for (int i = 0; i < (IGW_DIAG_FLAG(p, 4) ? 0 : m); i++) {  // _update, :222-262
-            const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
-            const double d = dt * speed;
-            const double ddx = mvx * d, ddz = mvz * d;
-            double ddy = mvy * d;
-            if (!FLY) {
-                e.vy -= dt * GRAVITY;
-                if (e.vy < -14.0) e.tis = 12;
-                else if (e.vy < -10.0) e.tis = 8;
-                else if (e.vy < -5.0) e.tis = 4;
-                else e.tis = 2;
-                e.vy = e.vy > -TERMINAL_VELOCITY ? e.vy : -TERMINAL_VELOCITY;
-            }
-            ddy += e.vy * dt;
-            double cx = e.x + ddx, cy = e.y + ddy, cz = e.z + ddz;
-            const bool in_zone = build_zone_d(cx, cy, cz, 2.0);
-            if (in_zone || !FLY) {
-                if (!in_zone) { cx = e.x; cz = e.z; }  // outside the padded zone a walker only moves vertically
-                if constexpr (GS >= 4) collide_split<GS>(G, e, occ_s, cx, cy, cz);
-                else collide(e, occ_s, cx, cy, cz);
-                e.x = cx; e.y = cy; e.z = cz;
-            }
-        }
-        if (FLY) e.vy = 0.0;
-    }
-    stamp(p, 3);
-    // yaw wrap with strict comparisons (0 and 360 both survive), :451-456
-    while (e.yaw > 360.0) e.yaw -= 360.0;
-    while (e.yaw < 0.0) e.yaw += 360.0;
     return ch;
 }
 
-// parse_walking_discrete_action (core/world.py:360-394) + World.step
-template <int GS>
-__device__ inline CellChange step_walking_action(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
-                                                 const int8_t* grid_g, const TrigCtx& trig, int action) {
-    double s0 = 0.0, s1 = 0.0, dy = 0.0, cam0 = 0.0, cam1 = 0.0;
-    int inventory = 0;
-    bool remove = false, add = false;
-    if (action == 1) s0 = -1.0;
-    else if (action == 2) s0 = 1.0;
-    else if (action == 3) s1 = -1.0;
-    else if (action == 4) s1 = 1.0;
-    else if (action == 5) dy = 1.0;
-    else if (action >= 6 && action <= 11) inventory = action - 5;
-    else if (action == 12) cam0 = -5.0;
-    else if (action == 13) cam0 = 5.0;
-    else if (action == 14) cam1 = -5.0;
-    else if (action == 15) cam1 = 5.0;
-    else if (action == 16) remove = true;
-    else if (action == 17) add = true;
-    return world_step<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, s0, s1, dy, inventory, cam0, cam1, remove, add);
+// remove_block's inventory refund (env.py:146-153 via the on_remove callback), once the colour has arrived
+__device__ inline void finish_break(Env& e, const CellChange& ch) {
+    if (ch.idx >= 0 && ch.new_val == 0) {
+        const int texture = ch.old_val;
+        if (texture >= 1 && texture <= 6) e.inv = inv_add(e.inv, texture - 1, 1);
+    }
+}
+
+// World.step second half: update(dt = 1/20) (core/world.py:203-262) and the yaw wrap (:451-456)
+template <int GS, int MODE>
+__device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, const uint32_t* occ_s,
+                                    const Motion& mv) {
+    constexpr bool FLY = MODE == MODE_FLY;
+    const int m = e.tis;
+    const double dt = m == 2 ? 0.05 / 2 : m == 4 ? 0.05 / 4 : m == 8 ? 0.05 / 8 : 0.05 / 12;
+    for (int i = 0; i < (IGW_DIAG_FLAG(p, 4) ? 0 : m); i++) {  // _update, :222-262
+        const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
+        const double d = dt * speed;
+        const double ddx = mv.x * d, ddz = mv.z * d;
+        double ddy = mv.y * d;
+        if (!FLY) {
+            e.vy -= dt * GRAVITY;
+            if (e.vy < -14.0) e.tis = 12;
+            else if (e.vy < -10.0) e.tis = 8;
+            else if (e.vy < -5.0) e.tis = 4;
+            else e.tis = 2;
+            e.vy = e.vy > -TERMINAL_VELOCITY ? e.vy : -TERMINAL_VELOCITY;
+        }
+        ddy += e.vy * dt;
+        double cx = e.x + ddx, cy = e.y + ddy, cz = e.z + ddz;
+        const bool in_zone = build_zone_d(cx, cy, cz, 2.0);
+        if (in_zone || !FLY) {
+            if (!in_zone) { cx = e.x; cz = e.z; }  // outside the padded zone a walker only moves vertically
+            if constexpr (GS >= 4) collide_split<GS>(G, e, occ_s, cx, cy, cz);
+            else collide(e, occ_s, cx, cy, cz);
+            e.x = cx; e.y = cy; e.z = cz;
+        }
+    }
+    if (FLY) e.vy = 0.0;
+    // yaw wrap with strict comparisons (0 and 360 both survive), :451-456
+    while (e.yaw > 360.0) e.yaw -= 360.0;
+    while (e.yaw < 0.0) e.yaw += 360.0;
+}
+
+// parse_walking_discrete_action (core/world.py:360-394)
+struct WalkAct {
+    double s0, s1, dy, cam0, cam1;
+    int inventory;
+    bool remove, add;
+};
+__device__ inline WalkAct parse_walking_discrete(int action) {
+    WalkAct w = {0.0, 0.0, 0.0, 0.0, 0.0, 0, false, false};
+    if (action == 1) w.s0 = -1.0;
+    else if (action == 2) w.s0 = 1.0;
+    else if (action == 3) w.s1 = -1.0;
+    else if (action == 4) w.s1 = 1.0;
+    else if (action == 5) w.dy = 1.0;
+    else if (action >= 6 && action <= 11) w.inventory = action - 5;
+    else if (action == 12) w.cam0 = -5.0;
+    else if (action == 13) w.cam0 = 5.0;
+    else if (action == 14) w.cam1 = -5.0;
+    else if (action == 15) w.cam1 = 5.0;
+    else if (action == 16) w.remove = true;
+    else if (action == 17) w.add = true;
+    return w;
 }
 
 // Task.step_intersection (tasks/task.py:103-119) part 1: block-count delta of the synthetic grid
@@ -320,27 +339,37 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int,
     return o;
 }
 
-// one pending histogram update: cell `cell` of env `env` changed its colour old_val -> new_val
+// ---------------------------------------------------------------- incremental maximal_intersection
+// tasks/task.py:147-161 as a persistent vote histogram (one 1 KB row per env: 4 rotations x 11 x 11
+// admissible translations, 16-bit counts).  A step changes at most one cell, so only the target cells on
+// that cell's y level can gain or lose a vote.  Per changed env the wave needs 1 KB of histogram, 121 bytes
+// of the synthetic target, one byte of the starting grid and the four bounding boxes.  All of it is fetched
+// by LDS-DMA (global_load_lds: no registers, no staging instructions) as soon as the change is known --
+// BEFORE the physics sub-steps -- so the loads are in flight while the wave computes, and the update itself
+// touches LDS only: votes are LDS atomics on the staged row, the new maximum is a reduction over the row
+// (always exact: no rescan path), and only the 16-byte pieces that changed go back to HBM.
+
 struct ChangeReq {
-    int env, task, cell, old_val, new_val, max_old;
+    int env, task, cell, old_val, new_val;
 };
-constexpr int REQ_MAX = 4;
-// changed envs handled together per pass: more keeps more loads in flight but costs ~13 VGPRs each;
-// wide groups rarely have more than one changed env per wave and are issue-bound, so they take 1
+// changed envs handled together per pass (one 1 KB LDS row each).  Groups of 4+ lanes rarely see more than
+// four changes in a wave; narrow groups pack many envs per wave and pay LDS for their occupancy rows.
 template <int GS>
-constexpr int req_chunk() { return GS >= 16 ? 1 : GS == 8 ? 2 : REQ_MAX; }
+constexpr int req_chunk() { return GS >= 4 ? 4 : GS == 2 ? 2 : 1; }
+constexpr int AUX_WORDS = 40;  // 32 dwords of target level + 1 dword with the start byte + 4 dwords of bounding boxes
+template <int R>
 struct WaveScratch {
-    ChangeReq req[REQ_MAX];
-    int incmax[REQ_MAX];
-    int decflag[REQ_MAX];
+    alignas(16) uint32_t hist[R][HIST_ROW / 2];
+    alignas(16) uint32_t aux[R][AUX_WORDS];
+    ChangeReq req[R];
 };
 
 template <int GS>
 struct BlockShared {
     static constexpr int EPB = BLOCK / GS;  // envs per block
     static constexpr int EPW = WAVE / GS;   // envs per wave
-    uint32_t occ[EPB * OCC_PITCH];  // occupancy bitmaps, one per env
-    WaveScratch ws[WAVES_PER_BLOCK];
+    alignas(16) uint32_t occ[EPB * OCC_PITCH];  // occupancy rows, one per env
+    WaveScratch<req_chunk<GS>()> ws[WAVES_PER_BLOCK];
 };
 
 __constant__ double IGW_TRIG_LUT_DEV[IGW_LUT_N * 2];
@@ -349,88 +378,144 @@ __constant__ double IGW_TRIG_LUT_DEV[IGW_LUT_N * 2];
 // LDS cost a block-wide barrier on every launch's critical path for a handful of lookups per step.
 __device__ inline const double* trig_lut() { return IGW_TRIG_LUT_DEV; }
 
-// the wave's EPW contiguous bitmap rows HBM -> LDS, coalesced dwordx4, LDS pitch OCC_PITCH
+// the wave's EPW contiguous bitmap rows HBM -> LDS (coalesced dwordx4 both ways), plus the constant words
 template <int GS>
 __device__ inline void load_occ_wave(const KParams& p, int first_env, uint32_t* occ_wave_s) {
     constexpr int EPW = WAVE / GS;
-    constexpr int CH = OCC_WORDS / 4;  // 9 chunks of 16 B per env
+    constexpr int CH = OCC_WORDS / 4;  // 12 chunks of 16 B per env
     const int lane = __lane_id();
     const int valid = min(EPW, p.n_envs - first_env);
     const uint4* src = reinterpret_cast<const uint4*>(p.occ + (size_t)first_env * OCC_WORDS);
     for (int c = lane; c < valid * CH; c += WAVE) {
         const uint4 v = src[c];
-        uint32_t* d = occ_wave_s + (c / CH) * OCC_PITCH + (c % CH) * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        *reinterpret_cast<uint4*>(occ_wave_s + (c / CH) * OCC_PITCH + OCC_VAR0 + (c % CH) * 4) = v;
+    }
+    // constant words: 4 lanes per env, lane part q writes the 16-byte pieces q of the prefix (words 4q..4q+3)
+    // and the zero words behind the variable part
+    const int q = lane & 3;
+    const uint4 pre = q == 0 ? make_uint4(occ_const_word(0), occ_const_word(1), occ_const_word(2), occ_const_word(3))
+                    : q == 1 ? make_uint4(occ_const_word(4), occ_const_word(5), occ_const_word(6), occ_const_word(7))
+                    : q == 2 ? make_uint4(occ_const_word(8), occ_const_word(9), occ_const_word(10), occ_const_word(11))
+                             : make_uint4(occ_const_word(12), occ_const_word(13), occ_const_word(14), occ_const_word(15));
+    static_assert(OCC_VAR0 == 16 && OCC_PITCH - OCC_VAR0 - OCC_WORDS == 8, "constant words are written as 4 + 2 pieces of 16 bytes");
+    for (int i = lane >> 2; i < EPW; i += WAVE / 4) {
+        uint32_t* row = occ_wave_s + i * OCC_PITCH;
+        *reinterpret_cast<uint4*>(row + 4 * q) = pre;
+        if (q < 2) *reinterpret_cast<uint4*>(row + OCC_VAR0 + OCC_WORDS + 4 * q) = make_uint4(0, 0, 0, 0);
     }
 }
 
-__device__ inline uint32_t ld_agent_u16(const uint16_t* ptr) {  // L2-served (a fused rollout re-reads its own stores)
-    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// LDS-DMA destination: the builtin only sets M0 (the wave-uniform LDS base) when it is handed a pointer that
+// is in the LDS address space by TYPE; through a generic pointer it silently emits the load without it.
+// (hipcc also parses device code in its host pass, where the gfx950 builtin does not exist: hence the guard.)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+#define IGW_LDS(p) ((lds_u32*)(uintptr_t)(uint32_t) reinterpret_cast<uintptr_t>(p))  /* low half of a flat LDS address = LDS offset */
+__device__ inline void glds16(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 16, 0, 0); }
+__device__ inline void glds16_sc1(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 16, 0, 16); }
+__device__ inline void glds4(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 4, 0, 0); }
+#else
+__device__ inline void glds16(const void*, uint32_t*) {}
+__device__ inline void glds16_sc1(const void*, uint32_t*) {}
+__device__ inline void glds4(const void*, uint32_t*) {}
+#endif
+
+// The LDS-DMA loads of one changed env into scratch slot k (whole wave).  L2: bypass this CU's L1 (the fused
+// rollout re-reads rows it stored earlier in the same launch).
+template <int R, bool L2>
+__device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, int k, const ChangeReq& rq) {
+    const int lane = __lane_id();
+    const char* hrow = reinterpret_cast<const char*>(p.hist + (size_t)rq.env * HIST_ROW) + 16 * lane;
+    if (L2) glds16_sc1(hrow, ws.hist[k]);  // cache policy sc1
+    else glds16(hrow, ws.hist[k]);
+    // lanes 0-31: the 128 bytes from the dword holding the first byte of the target level (a level is 121
+    // bytes at an arbitrary offset of the 16-byte aligned, 1104-byte row: never leaves the row);
+    // lane 32: the dword with the starting grid's byte of the cell; lanes 33-36: the four bounding boxes
+    const int8_t* t4 = p.task_target + (size_t)rq.task * STRIDE + (rq.cell / LEVEL) * LEVEL;
+    t4 -= reinterpret_cast<uintptr_t>(t4) & 3;
+    const int8_t* s4 = p.task_start + (size_t)rq.task * STRIDE + rq.cell;
+    s4 -= reinterpret_cast<uintptr_t>(s4) & 3;
+    const int8_t* b4 = p.task_meta[rq.task].bbox;
+    const int8_t* src = lane < 32 ? t4 + 4 * lane : lane == 32 ? s4 : b4 + 4 * (lane - 33);
+    if (lane < 37) glds4(src, ws.aux[k]);
 }
 
-// Incremental maximal_intersection (tasks/task.py:147-161 as a persistent vote histogram): a step changes
-// at most one cell, so only the target cells on that cell's y level can gain or lose a vote -- 121 bytes
-// of the synthetic target and a handful of 16-bit bins instead of target x grid.  The changed envs of the
-// wave are handled REQ_CHUNK at a time by all 64 lanes (lane l owns target cells l and l + 64 of the level),
-// and every global load of a chunk (target bytes, start byte, bounding boxes) is issued before the first
-// is consumed, so a chunk costs two memory round trips: {target, start, bbox} then {bins}.
-// Outputs per env: the largest value any incremented bin reached, and whether a bin that held
-// `max_old` was decremented (then the maximum has to be rescanned).
-template <int GS, bool DRAIN>
-__device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveScratch& ws, bool changed, int env,
-                                       int task, const CellChange& ch, int max_old, int& incmax_out,
-                                       bool& dec_out) {
-    incmax_out = 0;
-    dec_out = false;
-    const int lane = __lane_id();
+// Publishes the wave's changed envs and starts the DMA for the first chunk.  Returns the ballot of leaders.
+template <int GS, bool L2>
+__device__ inline uint64_t prefetch_changes(const Grp<GS>& G, const KParams& p, WaveScratch<req_chunk<GS>()>& ws,
+                                            bool changed, int env, int task, const CellChange& ch) {
+    constexpr int R = req_chunk<GS>();
     const bool leader = changed && G.gl == 0;
     const uint64_t mask = __ballot(leader);
-    if (mask == 0) return;
+    if (mask == 0) return 0;
+    const int my_k = __builtin_popcountll(mask & ((1ull << __lane_id()) - 1ull));
+    if (leader && my_k < R) {
+        ChangeReq& r = ws.req[my_k];
+        r.env = env; r.task = task; r.cell = ch.idx; r.old_val = 0; r.new_val = ch.new_val;
+    }
+    wave_sync();
+    const int cnt = min(R, __builtin_popcountll(mask));
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        if (k < cnt) dma_change_inputs<R, L2>(p, ws, k, ws.req[k]);
+    }
+    return mask;
+}
+
+// Applies the changes (after the DMA landed) and returns, per changed env, the new maximum of its histogram.
+template <int GS, bool L2>
+__device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveScratch<req_chunk<GS>()>& ws,
+                                      uint64_t mask, bool changed, int env, int task, const CellChange& ch) {
+    constexpr int R = req_chunk<GS>();
+    if (mask == 0) return 0;
+    const int lane = __lane_id();
+    const bool leader = changed && G.gl == 0;
     const int E = __builtin_popcountll(mask);
     const int my_k = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    constexpr int REQ_CHUNK = req_chunk<GS>();
     const bool v1 = lane + 64 < LEVEL;
-    int inc_l = 0, dec_l = 0;
-    for (int base = 0; base < E; base += REQ_CHUNK) {
-        const int cnt = min(REQ_CHUNK, E - base);
+    int hmax_l = 0;
+    for (int base = 0; base < E; base += R) {
+        const int cnt = min(R, E - base);
         const bool mine = leader && my_k >= base && my_k < base + cnt;
-        wave_sync();
-        if (mine) {
-            ChangeReq& r = ws.req[my_k - base];
-            r.env = env; r.task = task; r.cell = ch.idx; r.old_val = ch.old_val; r.new_val = ch.new_val;
-            r.max_old = max_old;
-            ws.incmax[my_k - base] = 0;
-            ws.decflag[my_k - base] = 0;
-        }
-        wave_sync();
-        ChangeReq rq[REQ_CHUNK];
-        int tv0[REQ_CHUNK], tv1[REQ_CHUNK], sv[REQ_CHUNK];
-        int4 bb[REQ_CHUNK];
+        if (base > 0) {  // more changed envs than scratch rows: fetch the next chunk now (rare)
+            wave_sync();
+            if (mine) {
+                ChangeReq& r = ws.req[my_k - base];
+                r.env = env; r.task = task; r.cell = ch.idx; r.new_val = ch.new_val;
+            }
+            wave_sync();
 #pragma unroll
-        for (int k = 0; k < REQ_CHUNK; k++) {
-            if (k < cnt) {
-                rq[k] = ws.req[k];
-                const int8_t* trow = p.task_target + (size_t)rq[k].task * STRIDE + (rq[k].cell / LEVEL) * LEVEL;
-                tv0[k] = trow[lane];
-                tv1[k] = v1 ? trow[lane + 64] : 0;
-                sv[k] = p.task_start[(size_t)rq[k].task * STRIDE + rq[k].cell];
-                bb[k] = *reinterpret_cast<const int4*>(p.task_meta[rq[k].task].bbox);
+            for (int k = 0; k < R; k++) {
+                if (k < cnt) dma_change_inputs<R, L2>(p, ws, k, ws.req[k]);
             }
         }
+        if (mine) ws.req[my_k - base].old_val = ch.old_val;  // the break's colour has arrived by now
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // DMA landed
+        wave_sync();
+        uint4 before[R];
 #pragma unroll
-        for (int k = 0; k < REQ_CHUNK; k++) {
+        for (int k = 0; k < R; k++) {
+            if (k < cnt) before[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < R; k++) {
             if (k < cnt) {
-                const int a = rq[k].old_val - sv[k], b = rq[k].new_val - sv[k];  // synthetic grid = grid - start
-                const int rem = rq[k].cell % LEVEL, gx = rem / 11, gz = rem % 11;
-                uint16_t* row = p.hist + (size_t)rq[k].env * HIST_ROW;
-                const int bbq[4] = {bb[k].x, bb[k].y, bb[k].z, bb[k].w};
+                const ChangeReq rq = ws.req[k];
+                const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) +
+                                   (reinterpret_cast<uintptr_t>(p.task_target + (size_t)rq.task * STRIDE + (rq.cell / LEVEL) * LEVEL) & 3);
+                const int sv = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)rq.task * STRIDE + rq.cell) & 3];
+                const int tv0 = tb[lane], tv1 = v1 ? tb[lane + 64] : 0;
+                const int a = rq.old_val - sv, b = rq.new_val - sv;  // synthetic grid = grid - start
+                const int rem = rq.cell % LEVEL, gx = rem / 11, gz = rem % 11;
+                const int bbq[4] = {(int)ws.aux[k][33], (int)ws.aux[k][34], (int)ws.aux[k][35], (int)ws.aux[k][36]};
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
-                    const int tval = half ? tv1[k] : tv0[k];
+                    const int tval = half ? tv1 : tv0;
                     const int j = lane + 64 * half;
                     const bool dec = tval != 0 && tval == a;
                     const bool inc = tval != 0 && tval == b;
-                    if (dec || inc) {
+                    if (dec != inc) {  // a cell whose colour did not change in the synthetic grid votes as before
                         const int tx = j / 11, tz = j % 11;
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
@@ -442,11 +527,8 @@ __device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveS
                             const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
                             if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (task.py:62-72)
                                 const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
-                                const int old = (int)ld_agent_u16(row + bin);
-                                const int nw = old + (inc ? 1 : -1);
-                                row[bin] = (uint16_t)nw;
-                                if (inc) atomicMax(&ws.incmax[k], nw);
-                                else if (old == rq[k].max_old) ws.decflag[k] = 1;
+                                const uint32_t one = 1u << (16 * (bin & 1));
+                                atomicAdd(&ws.hist[k][bin >> 1], inc ? one : 0u - one);
                             }
                         }
                     }
@@ -454,38 +536,22 @@ __device__ inline void resolve_changes(const Grp<GS>& G, const KParams& p, WaveS
             }
         }
         wave_sync();
-        if (mine) {
-            inc_l = ws.incmax[my_k - base];
-            dec_l = ws.decflag[my_k - base];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            if (k < cnt) {
+                const uint4 now = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+                if (now.x != before[k].x || now.y != before[k].y || now.z != before[k].z || now.w != before[k].w)
+                    reinterpret_cast<uint4*>(p.hist + (size_t)ws.req[k].env * HIST_ROW)[lane] = now;
+                const uint32_t m01 = max(max(now.x & 0xffff, now.x >> 16), max(now.y & 0xffff, now.y >> 16));
+                const uint32_t m23 = max(max(now.z & 0xffff, now.z >> 16), max(now.w & 0xffff, now.w >> 16));
+                const int best = wave_max_i32((int)max(m01, m23));
+                if (mine && my_k - base == k) hmax_l = best;
+            }
         }
     }
-    // the bins may be re-read later in this launch (rescan, next step of a fused rollout): let the stores
-    // land in L2 first; a plain step launch only needs that when a rescan follows
-    const int dec_any = __any(dec_l != 0);
-    if (DRAIN || dec_any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    incmax_out = G.bcast(inc_l, 0);
-    dec_out = G.bcast(dec_l, 0) != 0;
-}
-
-// full maximum over the env's histogram, one env at a time with all 64 lanes (rare)
-template <int GS>
-__device__ inline int resolve_rescans(const Grp<GS>& G, const KParams& p, bool want, int env, int cur) {
-    uint64_t m = __ballot(want && G.gl == 0);
-    if (m) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this launch's bin stores have reached L2
-    while (m) {
-        const int l = __builtin_ctzll(m);
-        m &= m - 1;
-        const int t_env = __builtin_amdgcn_readlane(env, l);
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(p.hist + (size_t)t_env * HIST_ROW);
-        int best = 0;
-        for (int w = __lane_id(); w < HIST_WORDS; w += WAVE) {
-            const uint32_t v = __hip_atomic_load(row + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            best = max(best, (int)max(v & 0xffff, v >> 16));
-        }
-        best = wave_max_i32(best);
-        if (__lane_id() / GS == l / GS) cur = best;
-    }
-    return cur;
+    // a fused rollout reads the rows again in its next step: let the stores reach L2 first
+    if (L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return G.bcast(hmax_l, 0);
 }
 
 // auto-reset rows of every done env of this wave (whole wave per env, coalesced)
@@ -524,21 +590,24 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     load_occ_wave<GS>(p, wave_env0, occ_wave_s);
     Env e = {};
     CellChange ch;
-    ch.idx = -1; ch.old_val = ch.new_val = 0;
+    ch.idx = -1; ch.bit = 0; ch.old_val = ch.new_val = 0;
+    Motion mv = {0.0, 0.0, 0.0};
     int size_new = 0, task = 0, env_max_int = 0, start_val = 0;
     bool need = false, has_start = false;
     const TaskMeta* meta = nullptr;
     int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
     [[maybe_unused]] int diag_m = 0;  // IGW_DIAG: sub-steps this env asked for
     if (active) {
-        task = p.env_task[env];  // prefetched: only consumed if the grid changes or the episode ends
+        task = p.env_task[env];
         env_load(e, p.agent + env);
         wave_sync();
         stamp(p, 1);
         diag_m = e.tis;
         e.step_no = min(e.step_no + 1, 65535);  // env.py:276
         if (MODE == MODE_WALK) {
-            ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, a.actions[env]);
+            const WalkAct w = parse_walking_discrete(a.actions[env]);
+            ch = world_act<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
+                                          w.remove, w.add, mv);
         } else if (MODE == MODE_WALK_DICT) {  // parse_walking_action, core/world.py:396-414
             const uint2 bw = *reinterpret_cast<const uint2*>(a.buttons + 8 * (size_t)env);
             const float* cam = a.camera + 2 * (size_t)env;
@@ -546,43 +615,48 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
             const bool jump = bw.y & 0xffu, attack = bw.y & 0xff00u, use = bw.y & 0xff0000u;
             const int hotbar = (int)(bw.y >> 24);
             const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
-            ch = world_step<GS, MODE_WALK_DICT>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar,
-                                                (double)cam[0], (double)cam[1], attack, use);
+            ch = world_act<GS, MODE_WALK_DICT>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar,
+                                               (double)cam[0], (double)cam[1], attack, use, mv);
         } else {  // parse_flying_action, core/world.py:416-432
-            const float* mv = a.movement + 3 * (size_t)env;
+            const float* mvm = a.movement + 3 * (size_t)env;
             const float* cam = a.camera + 2 * (size_t)env;
             const int placement = a.placement[env];
-            ch = world_step<GS, MODE_FLY>(G, p, e, occ_s, grid_g, trig, (double)mv[0], (double)mv[1], (double)mv[2],
-                                          a.inventory[env], (double)cam[0], (double)cam[1], placement == 2,
-                                          placement == 1);
+            ch = world_act<GS, MODE_FLY>(G, p, e, occ_s, grid_g, trig, (double)mvm[0], (double)mvm[1], (double)mvm[2],
+                                         a.inventory[env], (double)cam[0], (double)cam[1], placement == 2,
+                                         placement == 1, mv);
         }
-        // issued here, consumed after the histogram update (the work-item lanes fetch their own copy)
+        // issued here, consumed after the histogram update
         if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
         if (p.size_reward && e.step_no == 1) env_max_int = p.task_meta[task].env_max_int;
     }
-    stamp(p, 4);
-    int incmax = 0;
-    bool decd = false;
+    stamp(p, 2);
     const bool changed = active && ch.idx >= 0 && !IGW_DIAG_FLAG(p, 1);
-    resolve_changes<GS, false>(G, p, sh.ws[wave], changed, env, task, ch, e.max_int, incmax, decd);
+    // the histogram row, target level, start byte and bounding boxes of every changed env start moving into
+    // LDS now and land while the physics runs
+    const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env, task, ch);
+    if (active) {
+        if (MODE == MODE_FLY) world_update<GS, MODE_FLY>(G, p, e, occ_s, mv);
+        else world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
+        finish_break(e, ch);
+    }
+    stamp(p, 3);
+    stamp(p, 4);
+    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, changed, env, task, ch);
     size_new = e.prev_size;
     if (active && ch.idx >= 0) {
         size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
         need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
     }
     int mi = e.max_int;
-    bool rescan = false;
     if (changed) {
         if (need) {  // max_int = maximal_intersection(grid)
-            rescan = decd || e.dirty;
-            mi = max(mi, incmax);
+            mi = hmax;
             e.dirty = 0;
         } else {
             e.dirty = 1;  // the reference keeps its cached max_int here although the grid changed
         }
     }
     stamp(p, 5);
-    mi = resolve_rescans<GS>(G, p, rescan, env, mi);
     StepOut o;
     o.reward = 0.0; o.done = false;
     bool do_reset = false;
@@ -602,10 +676,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
 #ifdef IGW_DIAG
     {
         const unsigned long long n_ch = __builtin_popcountll(__ballot(changed && G.gl == 0));
-        const unsigned long long n_rs = __builtin_popcountll(__ballot(rescan && G.gl == 0));
         const unsigned long long n_rt = __builtin_popcountll(__ballot(do_reset && G.gl == 0));
         const unsigned long long n_hit = __builtin_popcountll(__ballot(ch.idx >= 0 && ch.new_val == 0 && G.gl == 0));
-        stamp_features(p, n_ch | (n_rs << 8) | (n_rt << 16) | ((unsigned long long)wave_max_i32(diag_m) << 24) | (n_hit << 32));
+        stamp_features(p, n_ch | (n_rt << 16) | ((unsigned long long)wave_max_i32(diag_m) << 24) | (n_hit << 32));
     }
 #endif
     if (!active) return;
@@ -613,7 +686,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     if (G.gl == 0) {
         if (ch.idx >= 0 && !do_reset) {
             grid_g[ch.idx] = (int8_t)ch.new_val;
-            p.occ[(size_t)env * OCC_WORDS + (ch.idx >> 5)] = occ_s[ch.idx >> 5];
+            p.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = occ_s[OCC_VAR0 + (ch.bit >> 5)];
         }
         p.reward[env] = (float)o.reward;
         p.done[env] = o.done ? 1 : 0;
@@ -621,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
         else write_step_obs(p, env, e);
         env_store(e, p.agent + env);
         if (need) stat_add(p.stats, IGW_STAT_CHANGED, 1);
-        if (rescan) stat_add(p.stats, IGW_STAT_RESCANS, 1);
+        if (ch.idx >= 0) stat_add(p.stats, IGW_STAT_RESCANS, 1);
         if (do_reset) stat_add(p.stats, IGW_STAT_RESETS, 1);
     }
     stamp(p, 6);
@@ -657,45 +730,48 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
         env_max_int = meta->env_max_int;
     }
     wave_sync();
-    unsigned long long n_changed = 0, n_resets = 0, n_rescans = 0;
+    unsigned long long n_changed = 0, n_resets = 0, n_updates = 0;
     StepOut o;
     o.reward = 0.0; o.done = false;
     bool last_reset = false;
     for (long long t = 0; t < T; t++) {
         CellChange ch;
-        ch.idx = -1; ch.old_val = ch.new_val = 0;
-        int size_new = 0;
+        ch.idx = -1; ch.bit = 0; ch.old_val = ch.new_val = 0;
+        Motion mv = {0.0, 0.0, 0.0};
+        int size_new = 0, start_val = 0;
         bool need = false;
         if (active) {
             e.step_no = min(e.step_no + 1, 65535);
-            const int action = rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
-            ch = step_walking_action<GS>(G, p, e, occ_s, grid_g, trig, action);
-            int start_val = 0;
+            const WalkAct w = parse_walking_discrete(rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t)));
+            ch = world_act<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
+                                          w.remove, w.add, mv);
             if (ch.idx >= 0 && has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
+        }
+        const bool changed = active && ch.idx >= 0;
+        const uint64_t chg_mask = prefetch_changes<GS, true>(G, p, sh.ws[wave], changed, env, task, ch);
+        if (active) {
+            world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
+            finish_break(e, ch);
+        }
+        const int hmax = resolve_changes<GS, true>(G, p, sh.ws[wave], chg_mask, changed, env, task, ch);
+        if (active) {
             size_new = e.prev_size + syn_size_delta(ch, start_val);
             need = size_new != e.prev_size;
         }
-        int incmax = 0;
-        bool decd = false;
-        const bool changed = active && ch.idx >= 0;
-        resolve_changes<GS, true>(G, p, sh.ws[wave], changed, env, task, ch, e.max_int, incmax, decd);
         int mi = e.max_int;
-        bool rescan = false;
         if (changed) {
             if (need) {
-                rescan = decd || e.dirty;
-                mi = max(mi, incmax);
+                mi = hmax;
                 e.dirty = 0;
             } else {
                 e.dirty = 1;
             }
         }
-        mi = resolve_rescans<GS>(G, p, rescan, env, mi);
         bool do_reset = false;
         if (active) {
             o = finish_step(p, e, env_max_int, size_new, mi);
             n_changed += need;
-            n_rescans += rescan;
+            n_updates += changed;
             do_reset = o.done;
             last_reset = do_reset;
             // colours go to HBM right away (a later break of this launch reads them)
@@ -719,7 +795,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
     }
     if (!active) return;
     wave_sync();
-    for (int w = G.gl; w < OCC_WORDS; w += GS) p.occ[(size_t)env * OCC_WORDS + w] = occ_s[w];
+    for (int w = G.gl; w < OCC_WORDS; w += GS) p.occ[(size_t)env * OCC_WORDS + w] = occ_s[OCC_VAR0 + w];
     if (G.gl == 0) {
         p.reward[env] = (float)o.reward;
         p.done[env] = o.done ? 1 : 0;
@@ -728,7 +804,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
         env_store(e, p.agent + env);
         if (n_changed) stat_add(p.stats, IGW_STAT_CHANGED, n_changed);
         if (n_resets) stat_add(p.stats, IGW_STAT_RESETS, n_resets);
-        if (n_rescans) stat_add(p.stats, IGW_STAT_RESCANS, n_rescans);
+        if (n_updates) stat_add(p.stats, IGW_STAT_RESCANS, n_updates);
         stat_add(p.stats, IGW_STAT_STEPS, (unsigned long long)T);
     }
 }
@@ -865,12 +941,15 @@ __global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int fir
         const uint4* s = reinterpret_cast<const uint4*>(S);
         uint4* d = reinterpret_cast<uint4*>(const_cast<int8_t*>(p.task_start) + (size_t)task * STRIDE);
         for (int c = lane; c < CHUNKS; c += WAVE) d[c] = s[c];
-        // occupancy bitmap of the starting grid: lane w packs cells 32w .. 32w+31
+        // occupancy bitmap of the starting grid in the padded 9 x 13 x 13 layout (igw_device.h): lane w packs
+        // bits 32w .. 32w+31
         if (lane < OCC_WORDS) {
             uint32_t bits = 0;
             for (int k = 0; k < 32; k++) {
-                const int c = lane * 32 + k;
-                if (c < CELLS && S[c] != 0) bits |= 1u << k;
+                const int i = lane * 32 + k, yv = i / OCC_LAYER, r = i % OCC_LAYER, xp = r / 13, zp = r % 13;
+                if (yv < IGW_GRID_Y && xp >= 1 && xp <= 11 && zp >= 1 && zp <= 11 &&
+                    S[yv * LEVEL + (xp - 1) * 11 + (zp - 1)] != 0)
+                    bits |= 1u << k;
             }
             const_cast<uint32_t*>(p.task_start_occ)[(size_t)task * OCC_WORDS + lane] = bits;
         }

@@ -48,9 +48,11 @@ extern "C" {
 /* row stride of every [*, 9,11,11] int8 buffer: 1089 padded to a multiple of 16 B so a
  * wavefront moves one env's grid with 69 aligned dwordx4 accesses; pad bytes stay 0 */
 #define IGW_GRID_STRIDE 1104
-/* occupancy bitmap of the 1089 cells (bit = cell index), 36 dwords = 144 B per env: the per-step
- * working set of the physics; kept in sync with `grid` by every kernel */
-#define IGW_OCC_WORDS 36
+/* occupancy bitmap, 48 dwords = 192 B per env: the per-step working set of the physics, kept in sync with
+ * `grid` by every kernel.  One bit per cell of the 9 x 13 x 13 box that pads each y level of the build zone
+ * with one always-empty cell on every side in x and z: bit = (y+1)*169 + (x+6)*13 + (z+6) for the cell at
+ * world (x, y, z), i.e. grid[y+1][x+5][z+5]; padding bits and bits >= 1521 stay 0 */
+#define IGW_OCC_WORDS 48
 /* persistent per-env vote histogram of maximal_intersection: for each of the 4 rotations the 11 x 11
  * admissible translations (bounding-box relative), uint16 counts, row padded to 512 entries */
 #define IGW_HIST_ROW 512
@@ -62,7 +64,7 @@ extern "C" {
 #define IGW_STAT_CHANGED 0 /* env-steps whose block count changed (max_intersection recomputed) */
 #define IGW_STAT_RESETS 1  /* auto-resets performed */
 #define IGW_STAT_STEPS 2   /* env-steps executed by igw_rollout_walking */
-#define IGW_STAT_RESCANS 3 /* full histogram rescans (a bin holding the maximum was decremented) */
+#define IGW_STAT_RESCANS 3 /* histogram row updates (env-steps that changed a cell; each takes the row maximum) */
 
 enum igw_status {
     IGW_OK = 0,

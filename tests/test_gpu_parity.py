@@ -175,13 +175,17 @@ def _check_hist(env, targets, starts=None, sample=None):
 
 
 def _check_occ(env):
+    """HBM occupancy rows == the grid in the padded 9 x 13 x 13 bit layout of include/igw.h."""
     torch.cuda.synchronize()
-    g = env.grid.cpu().numpy().reshape(env.num_envs, -1) != 0
-    bits = np.zeros((env.num_envs, 36 * 32), bool)
-    bits[:, :1089] = g
-    want = np.packbits(bits.reshape(env.num_envs, 36, 32), axis=-1, bitorder='little').view(np.uint32)[:, :, 0]
+    n = env.num_envs
+    g = env.grid.cpu().numpy().reshape(n, 9, 11, 11) != 0
+    box = np.zeros((n, 9, 13, 13), bool)
+    box[:, :, 1:12, 1:12] = g
+    bits = np.zeros((n, 48 * 32), bool)
+    bits[:, :9 * 169] = box.reshape(n, -1)
+    want = np.packbits(bits.reshape(n, 48, 32), axis=-1, bitorder='little').view(np.uint32)[:, :, 0]
     got = env.occ_buf.cpu().numpy().view(np.uint32)
-    assert np.array_equal(got, want), 'occupancy bitmap out of sync with the grid'
+    assert got.shape == want.shape and np.array_equal(got, want), 'occupancy bitmap out of sync with the grid'
 
 
 @pytest.mark.parametrize('gs', [0, 16, 1])
@@ -249,7 +253,7 @@ def test_start_grids_incremental_reward_vs_oracle(gs):
     stt = env.stats()
     ts = env.task_state()
     print('changed', stt['changed'], 'rescans', stt['rescans'], 'dirty now', int(ts['dirty'].sum()))
-    assert stt['rescans'] > 0
+    assert stt['rescans'] > 0   # histogram row updates
     _check_hist(env, tg, st, sample=range(0, n, 5))
     _check_occ(env)
 
