@@ -279,6 +279,8 @@ def main():
         for t in range(W, W + K):
             step(t)
     ev1.record()
+    while not ev1.query():  # spin: a blocking synchronize sleeps on an interrupt and wakes tens of microseconds late
+        pass
     torch.cuda.synchronize(device)
     gdist.barrier(device)
     elapsed = time.perf_counter() - t_start

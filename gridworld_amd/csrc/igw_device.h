@@ -155,6 +155,12 @@ struct Grp {
         else if constexpr (GS == 4) return dpp_quad<QUAD_SHIFT_UP>(v);
         else return __shfl_up(v, 1, GS);
     }
+    // value of the group's first lane
+    __device__ int bcast_first(int v) const {
+        if constexpr (GS == 1) return v;
+        else if constexpr (GS == 4) return dpp_quad<QUAD_BCAST0>(v);
+        else return bcast(v, 0);
+    }
     // value of the group's last lane
     __device__ int bcast_last(int v) const {
         if constexpr (GS == 1) return v;
@@ -178,6 +184,18 @@ __device__ inline void wave_sync() {
     // from moving LDS accesses of different lanes across the point.
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// wave-wide maximum of NON-NEGATIVE ints on the DPP network (row shifts, then the two row broadcasts), result
+// uniform: no trip through the LDS crossbar.  Lanes without a source read 0.
+__device__ inline int wave_max_nonneg(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false));  // row_shr:8  -> lane 15 of a row = row max
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ inline int wave_max_i32(int v) {

@@ -492,38 +492,46 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         if (mine) ws.req[my_k - base].old_val = ch.old_val;  // the break's colour has arrived by now
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // DMA landed
         wave_sync();
+        // Three batched phases over all slots, so their LDS round trips overlap instead of chaining per env.
+        // Slots beyond cnt hold stale but in-bounds data; they are read and ignored.
+        ChangeReq rq[R];
         uint4 before[R];
+        int tv0[R], tv1[R], sv[R], bbq[R][4];
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            if (k < cnt) before[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+            rq[k] = ws.req[k];
+            before[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+#pragma unroll
+            for (int q = 0; q < 4; q++) bbq[k][q] = (int)ws.aux[k][33 + q];
         }
-        wave_sync();
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int8_t* trow = p.task_target + (size_t)rq[k].task * STRIDE + (rq[k].cell / LEVEL) * LEVEL;
+            const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) + (reinterpret_cast<uintptr_t>(trow) & 3);
+            tv0[k] = tb[lane];
+            tv1[k] = v1 ? tb[lane + 64] : 0;
+            sv[k] = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)rq[k].task * STRIDE + rq[k].cell) & 3];
+        }
 #pragma unroll
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
-                const ChangeReq rq = ws.req[k];
-                const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) +
-                                   (reinterpret_cast<uintptr_t>(p.task_target + (size_t)rq.task * STRIDE + (rq.cell / LEVEL) * LEVEL) & 3);
-                const int sv = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)rq.task * STRIDE + rq.cell) & 3];
-                const int tv0 = tb[lane], tv1 = v1 ? tb[lane + 64] : 0;
-                const int a = rq.old_val - sv, b = rq.new_val - sv;  // synthetic grid = grid - start
-                const int rem = rq.cell % LEVEL, gx = rem / 11, gz = rem % 11;
-                const int bbq[4] = {(int)ws.aux[k][33], (int)ws.aux[k][34], (int)ws.aux[k][35], (int)ws.aux[k][36]};
+                const int a = rq[k].old_val - sv[k], b = rq[k].new_val - sv[k];  // synthetic grid = grid - start
+                const int rem = rq[k].cell % LEVEL, gx = rem / 11, gz = rem % 11;
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
-                    const int tval = half ? tv1 : tv0;
+                    const int tval = half ? tv1[k] : tv0[k];
                     const int j = lane + 64 * half;
                     const bool dec = tval != 0 && tval == a;
                     const bool inc = tval != 0 && tval == b;
-                    if (dec != inc) {  // a cell whose colour did not change in the synthetic grid votes as before
+                    if (dec != inc) {  // (a cell that matched before and after cannot exist: a != b)
                         const int tx = j / 11, tz = j % 11;
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
                             const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
                             const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
-                            const int xmin = (int8_t)(bbq[q] & 0xff), xmax = (int8_t)((bbq[q] >> 8) & 0xff);
-                            const int zmin = (int8_t)((bbq[q] >> 16) & 0xff), zmax = (int8_t)((bbq[q] >> 24) & 0xff);
+                            const int xmin = (int8_t)(bbq[k][q] & 0xff), xmax = (int8_t)((bbq[k][q] >> 8) & 0xff);
+                            const int zmin = (int8_t)((bbq[k][q] >> 16) & 0xff), zmax = (int8_t)((bbq[k][q] >> 24) & 0xff);
                             const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
                             if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (task.py:62-72)
                                 const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
@@ -536,22 +544,24 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
             }
         }
         wave_sync();
+        uint4 now[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) now[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
 #pragma unroll
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
-                const uint4 now = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
-                if (now.x != before[k].x || now.y != before[k].y || now.z != before[k].z || now.w != before[k].w)
-                    reinterpret_cast<uint4*>(p.hist + (size_t)ws.req[k].env * HIST_ROW)[lane] = now;
-                const uint32_t m01 = max(max(now.x & 0xffff, now.x >> 16), max(now.y & 0xffff, now.y >> 16));
-                const uint32_t m23 = max(max(now.z & 0xffff, now.z >> 16), max(now.w & 0xffff, now.w >> 16));
-                const int best = wave_max_i32((int)max(m01, m23));
+                if (now[k].x != before[k].x || now[k].y != before[k].y || now[k].z != before[k].z || now[k].w != before[k].w)
+                    reinterpret_cast<uint4*>(p.hist + (size_t)rq[k].env * HIST_ROW)[lane] = now[k];
+                const uint32_t m01 = max(max(now[k].x & 0xffff, now[k].x >> 16), max(now[k].y & 0xffff, now[k].y >> 16));
+                const uint32_t m23 = max(max(now[k].z & 0xffff, now[k].z >> 16), max(now[k].w & 0xffff, now[k].w >> 16));
+                const int best = wave_max_nonneg((int)max(m01, m23));
                 if (mine && my_k - base == k) hmax_l = best;
             }
         }
     }
     // a fused rollout reads the rows again in its next step: let the stores reach L2 first
     if (L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return G.bcast(hmax_l, 0);
+    return G.bcast_first(hmax_l);
 }
 
 // auto-reset rows of every done env of this wave (whole wave per env, coalesced)
