@@ -15,16 +15,18 @@ CELLS = 1089
 AGENT_BYTES = 64
 TASK_META_BYTES = 128
 OCC_WORDS = 48
+TRAJ_BYTES = 64
 HIST_ROW = 512
 STAT_STRIPES = 64
-STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS = 0, 1, 2, 3
+STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS, STAT_BAD_POSE, STAT_BAD_ACTION = 0, 1, 2, 3, 4, 5
+VERSION = 2
 WALKING_DISCRETE, FLYING, WALKING_DICT = 0, 1, 2
 RESET_KEEP_SIZE = 1
 
 # every symbol include/igw.h declares (checked by tests/test_abi.py)
 EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',
-           'igw_bind_buffers', 'igw_prepare_tasks', 'igw_set_task_sampling', 'igw_reset', 'igw_step_walking', 'igw_step_flying',
-           'igw_step_walking_dict',
+           'igw_bind_buffers', 'igw_prepare_tasks', 'igw_set_task_sampling', 'igw_set_random_tasks',
+           'igw_set_trajectory_log', 'igw_reset', 'igw_step_walking', 'igw_step_flying', 'igw_step_walking_dict',
            'igw_rollout_walking', 'igw_fill_actions_walking', 'igw_task_eval']
 
 
@@ -37,13 +39,13 @@ class Config(C.Structure):
                 ('action_space', C.c_int32), ('select_and_place', C.c_int32), ('size_reward', C.c_int32),
                 ('max_steps', C.c_int32), ('autoreset', C.c_int32),
                 ('right_placement_scale', C.c_double), ('wrong_placement_scale', C.c_double),
-                ('lanes_per_env', C.c_int32), ('reserved', C.c_int32)]
+                ('lanes_per_env', C.c_int32), ('reserved', C.c_int32), ('env_index_base', C.c_int64)]
 
 
 class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('grid', 'occ', 'hist', 'agent', 'env_task', 'task_target', 'task_start',
                                           'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass',
-                                          'reward', 'done', 'stats')]
+                                          'reward', 'done', 'stats', 'episode')]
 
 
 _lib = None
@@ -79,7 +81,9 @@ def load(build_if_missing=True):
     L.igw_bind_buffers.argtypes = [vp, C.POINTER(Buffers)]
     L.igw_prepare_tasks.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.igw_reset.argtypes = [vp, vp, i32, vp]
-    L.igw_set_task_sampling.argtypes = [vp, i32, u64]
+    L.igw_set_task_sampling.argtypes = [vp, i32, u64, i32]
+    L.igw_set_random_tasks.argtypes = [vp, i32, u64, i32, i32, i32, i32, vp]
+    L.igw_set_trajectory_log.argtypes = [vp, vp, vp, i32, i32]
     L.igw_step_walking.argtypes = [vp, vp, vp]
     L.igw_step_flying.argtypes = [vp, vp, vp, vp, vp, vp]
     L.igw_step_walking_dict.argtypes = [vp, vp, vp, vp]

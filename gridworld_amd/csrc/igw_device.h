@@ -88,8 +88,10 @@ struct KParams {
     int32_t n_envs, select_and_place, size_reward, max_steps, autoreset;
     int32_t debug;  // timing-only ablation switches (igw_config.reserved); 0 in every parity / bench run
     int32_t sample_tasks, n_tasks;  // igw_set_task_sampling: draw env_task uniformly from the table at every reset
+    int32_t rt_enabled, rt_max_blocks, rt_levels, rt_max_dist, rt_colors;  // igw_set_random_tasks
+    int32_t traj_n, traj_cap;       // igw_set_trajectory_log: envs logged, steps per episode slot
     unsigned long long sample_seed;
-    long long tick;                 // launches so far (keys the sampler)
+    long long env_base;             // igw_config.env_index_base: global index of env 0 (keys the samplers)
     double right_scale, wrong_scale;
     int8_t* grid;
     uint32_t* occ;
@@ -106,6 +108,9 @@ struct KParams {
     float* reward;
     uint8_t* done;
     unsigned long long* stats;
+    uint32_t* episode;           // [N] episodes started per env (keys the samplers and the trajectory log)
+    uint8_t* traj;               // [traj_n][2][traj_cap][IGW_TRAJ_BYTES]
+    int32_t* traj_heads;         // [traj_n][2][4]
     unsigned long long* stamps;  // diagnostic builds only: [waves][8] s_memtime stamps (igw_debug_set_stamps)
 };
 
@@ -217,11 +222,20 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-// uniform task index in [0, n): CustomTasks.reset() (gridworld/tasks/task_set.py:53-56) on the device
-__host__ __device__ inline int rng_task(uint64_t seed, uint64_t env, uint64_t tick, int n) {
-    uint64_t h = splitmix64(seed ^ splitmix64(env * 0x9E3779B1ull + tick * 0x100000001B3ull + 0x7461736bull));
+// uniform task index in [0, n): CustomTasks.reset() (gridworld/tasks/task_set.py:53-56) on the device,
+// keyed by (seed, global env index, number of the episode that ends)
+__host__ __device__ inline int rng_task(uint64_t seed, uint64_t env, uint64_t episode, int n) {
+    uint64_t h = splitmix64(seed ^ splitmix64(env * 0x9E3779B1ull + episode * 0x100000001B3ull + 0x7461736bull));
     return (int)(((h >> 32) * (uint64_t)n) >> 32);
 }
+// 32-bit counter hash for the random-task generator (murmur3 finaliser over a running combination)
+__host__ __device__ inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ inline uint32_t hash_combine(uint32_t h, uint32_t v) { return fmix32(h ^ (v + 0x9E3779B9u + (h << 6) + (h >> 2))); }
+// uniform integer in [0, n) from 32 random bits
+__host__ __device__ inline int rng_below(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)n) >> 32); }
 __host__ __device__ inline int rng_action18(uint64_t seed, uint64_t env, uint64_t t) {
     uint64_t h = splitmix64(seed ^ splitmix64(env * 0x100000001B3ull + t));
     return (int)(((h >> 32) * 18ull) >> 32);

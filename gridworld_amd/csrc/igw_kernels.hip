@@ -65,22 +65,165 @@ __device__ inline void stat_add(unsigned long long* stats, int which, unsigned l
     if (stats) atomicAdd(&stats[(blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + which], v);
 }
 
-// per-lane part of GridWorld.reset (env.py:206-261): everything except the grid / bitmap rows
-__device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_size) {
+struct BBox {
+    int xmin, xmax, zmin, zmax;
+};
+
+// bounding box of the non-zero cells of an LDS row (wave-wide); empty -> (10, 0, 10, 0)
+__device__ inline BBox row_bbox(const int8_t* row_s, int& nnz) {
+    const int lane = __lane_id();
+    int xmin = 10, xmax = 0, zmin = 10, zmax = 0, cnt = 0;
+    for (int c = lane; c < CELLS; c += WAVE) {
+        if (row_s[c] != 0) {
+            const int r = c % LEVEL, x = r / 11, z = r % 11;
+            xmin = min(xmin, x); xmax = max(xmax, x);
+            zmin = min(zmin, z); zmax = max(zmax, z);
+            cnt++;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    nnz = cnt;
+    BBox b;
+    b.xmin = wave_min_i32(xmin); b.xmax = wave_max_i32(xmax);
+    b.zmin = wave_min_i32(zmin); b.zmax = wave_max_i32(zmax);
+    if (cnt == 0) { b.xmin = 10; b.xmax = 0; b.zmin = 10; b.zmax = 0; }
+    return b;
+}
+
+__device__ inline int pack_bbox(int xmin, int xmax, int zmin, int zmax) {
+    return (xmin & 0xff) | ((xmax & 0xff) << 8) | ((zmin & 0xff) << 16) | ((zmax & 0xff) << 24);
+}
+// bboxes of the 4 rotations (x,z) -> (z, 10-x) (tasks/task.py:52-53) of a box; admissible translations
+// of rotation r are dx in [xmax-10, xmin], dz in [zmax-10, zmin] (tasks/task.py:62-72 as a bbox rule)
+__device__ inline void rot_bboxes(const BBox& b, bool empty, int* out4) {
+    if (empty) {
+        out4[0] = out4[1] = out4[2] = out4[3] = pack_bbox(10, 0, 10, 0);
+        return;
+    }
+    out4[0] = pack_bbox(b.xmin, b.xmax, b.zmin, b.zmax);
+    out4[1] = pack_bbox(b.zmin, b.zmax, 10 - b.xmax, 10 - b.xmin);
+    out4[2] = pack_bbox(10 - b.xmax, 10 - b.xmin, 10 - b.zmax, 10 - b.zmin);
+    out4[3] = pack_bbox(10 - b.zmax, 10 - b.zmin, b.xmin, b.xmax);
+}
+
+// per-lane part of GridWorld.reset (env.py:206-261): everything except the grid / bitmap rows.
+// generated_size >= 0: the task row was just written by the on-device RandomTasks generator of this wave (its
+// metadata is taken from registers, not re-read: target size as given, empty start => full inventory).
+__device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_size, int generated_size = -1) {
     if (!keep_size) e.size = 0;  // SizeReward.reset, env.py:321-323
     e.step_no = 0;               // env.py:217
     e.prev_size = 0;             // _synthetic_task.reset(): prev_grid_size = 0, max_int = 0 (task.py:74-86)
     e.max_int = 0;
     e.dirty = 0;
-    e.target_size = meta->target_size;
     e.x = meta->pose[0]; e.y = meta->pose[1]; e.z = meta->pose[2];  // env.py:239-240
     e.yaw = meta->pose[3]; e.pitch = meta->pose[4];
-    uint64_t inv = 0;  // env.py:243-246
+    if (generated_size >= 0) {
+        e.target_size = generated_size;
+        e.inv = 0x141414141414ull;  // 20 of each colour
+    } else {
+        e.target_size = meta->target_size;
+        uint64_t inv = 0;  // env.py:243-246
 #pragma unroll
-    for (int i = 0; i < 6; i++) inv |= (uint64_t)(uint8_t)meta->inv_init[i] << (8 * i);
-    e.inv = inv;
+        for (int i = 0; i < 6; i++) inv |= (uint64_t)(uint8_t)meta->inv_init[i] << (8 * i);
+        e.inv = inv;
+    }
     // agent.dy, time_int_steps, active_block are NOT reset by the reference
 }
+
+// A reset counts a new episode and, with a task generator on the device, picks the env's next task row.
+// Returns the number of the episode that ends (the samplers' key).  `leader`: the one lane that stores.
+__device__ inline uint32_t next_task(const KParams& p, int env, bool leader, int& task) {
+    uint32_t ep = 0;
+    if (p.episode) {
+        ep = __hip_atomic_load(p.episode + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (leader) p.episode[env] = ep + 1;
+    }
+    if (p.sample_tasks) {  // CustomTasks.reset on the device: uniform choice over the table
+        task = rng_task(p.sample_seed, (uint64_t)(p.env_base + env), (uint64_t)ep, p.n_tasks);
+        if (leader) p.env_task[env] = task;
+    } else if (p.rt_enabled) {  // RandomTasks.sample_task on the device: the env's own row is regenerated
+        task = env;
+        if (leader) p.env_task[env] = env;
+    }
+    return ep;
+}
+
+// RandomTasks.sample_task (gridworld/tasks/task_set.py:135-157) for one env by the whole wave: per height level
+// the first block uniform over the plane, then K = min(max_blocks - 1, free window cells) further blocks on
+// distinct cells within Chebyshev distance max_dist of it.  The reference draws them one at a time by rejection,
+// i.e. uniformly without replacement, so the occupied set is a uniformly random K-subset of the window; here
+// every window cell gets a random 32-bit key and the K smallest win (ties by cell index).  Colours are iid
+// uniform in 1..num_colors.  row_s: 1104 bytes of LDS scratch.  Writes the task's target row and the generated
+// part of its metadata (the init pose is kept); returns the number of blocks (= target_size).
+__device__ inline int sample_random_task_wave(const KParams& p, int env, uint32_t ep, int8_t* row_s) {
+    const int lane = __lane_id();
+    uint4* r4 = reinterpret_cast<uint4*>(row_s);
+    for (int c = lane; c < CHUNKS; c += WAVE) r4[c] = make_uint4(0, 0, 0, 0);
+    wave_sync();
+    const unsigned long long genv = (unsigned long long)(p.env_base + env);
+    uint32_t h0 = hash_combine((uint32_t)p.sample_seed, (uint32_t)(p.sample_seed >> 32));
+    h0 = hash_combine(hash_combine(hash_combine(h0, (uint32_t)genv), (uint32_t)(genv >> 32)), ep);
+    const int d = p.rt_max_dist, ncol = p.rt_colors;
+    int total = 0, xmin = 10, xmax = 0, zmin = 10, zmax = 0;
+    for (int lvl = 0; lvl < p.rt_levels; lvl++) {
+        const uint32_t hl = hash_combine(h0, 0x1000u + (uint32_t)lvl);
+        const int bx = rng_below(hash_combine(hl, 0x20001u), IGW_GRID_X), bz = rng_below(hash_combine(hl, 0x20002u), IGW_GRID_Z);
+        const int x0 = max(bx - d, 0), x1 = min(bx + d, IGW_GRID_X - 1), z0 = max(bz - d, 0), z1 = min(bz + d, IGW_GRID_Z - 1);
+        const int K = min(p.rt_max_blocks - 1, (x1 - x0 + 1) * (z1 - z0 + 1) - 1);
+        // this lane's two plane cells
+        const int c0 = lane, c1 = lane + 64;
+        const int cx0 = c0 / 11, cz0 = c0 % 11, cx1 = c1 / 11, cz1 = c1 % 11;
+        const bool w0 = cx0 >= x0 && cx0 <= x1 && cz0 >= z0 && cz0 <= z1 && !(cx0 == bx && cz0 == bz);
+        const bool w1 = c1 < LEVEL && cx1 >= x0 && cx1 <= x1 && cz1 >= z0 && cz1 <= z1 && !(cx1 == bx && cz1 == bz);
+        const uint32_t k0 = hash_combine(hl, (uint32_t)c0), k1 = hash_combine(hl, (uint32_t)c1);
+        int rank0 = 0, rank1 = 0;
+        for (int x = x0; x <= x1; x++) {
+            for (int z = z0; z <= z1; z++) {
+                const int j = x * 11 + z;
+                if (x == bx && z == bz) continue;
+                const uint32_t kj = hash_combine(hl, (uint32_t)j);
+                rank0 += (kj < k0 || (kj == k0 && j < c0)) ? 1 : 0;
+                rank1 += (kj < k1 || (kj == k1 && j < c1)) ? 1 : 0;
+            }
+        }
+        const bool s0 = w0 && rank0 < K, s1 = w1 && rank1 < K;
+        const bool f0 = cx0 == bx && cz0 == bz, f1 = c1 < LEVEL && cx1 == bx && cz1 == bz;  // the first block
+        if (s0 || f0) row_s[lvl * LEVEL + c0] = (int8_t)(1 + rng_below(hash_combine(hl, 0x10000u + (uint32_t)c0), ncol));
+        if (s1 || f1) row_s[lvl * LEVEL + c1] = (int8_t)(1 + rng_below(hash_combine(hl, 0x10000u + (uint32_t)c1), ncol));
+        total += K + 1;
+        int lxmin = 10, lxmax = 0, lzmin = 10, lzmax = 0;
+        if (s0 || f0) { lxmin = cx0; lxmax = cx0; lzmin = cz0; lzmax = cz0; }
+        if (s1 || f1) { lxmin = min(lxmin, cx1); lxmax = max(lxmax, cx1); lzmin = min(lzmin, cz1); lzmax = max(lzmax, cz1); }
+        xmin = min(xmin, wave_min_i32(lxmin)); xmax = max(xmax, wave_max_i32(lxmax));
+        zmin = min(zmin, wave_min_i32(lzmin)); zmax = max(zmax, wave_max_i32(lzmax));
+    }
+    wave_sync();
+    uint4* dst = reinterpret_cast<uint4*>(const_cast<int8_t*>(p.task_target) + (size_t)env * STRIDE);
+    for (int c = lane; c < CHUNKS; c += WAVE) dst[c] = r4[c];
+    if (lane == 0) {
+        // bytes 40..69 of the metadata row (task.py:9-72 on an empty start): target_size, GridWorld.max_int = 0,
+        // has_start = 0, the four rotation bounding boxes, inventory 20 x 6
+        TaskMeta* m = const_cast<TaskMeta*>(p.task_meta) + env;
+        BBox b;
+        b.xmin = xmin; b.xmax = xmax; b.zmin = zmin; b.zmax = zmax;
+        int bb[4];
+        rot_bboxes(b, total == 0, bb);
+        m->target_size = (int16_t)total;
+        m->env_max_int = 0;
+        m->has_start = 0;
+        for (int k = 0; k < 4; k++) {
+            m->bbox[4 * k + 0] = (int8_t)(bb[k] & 0xff);
+            m->bbox[4 * k + 1] = (int8_t)((bb[k] >> 8) & 0xff);
+            m->bbox[4 * k + 2] = (int8_t)((bb[k] >> 16) & 0xff);
+            m->bbox[4 * k + 3] = (int8_t)((bb[k] >> 24) & 0xff);
+        }
+        for (int k = 0; k < 6; k++) m->inv_init[k] = 20;
+    }
+    wave_sync();
+    return total;
+}
+
 
 // whole-wave copy of the starting grid and its occupancy bitmap into one env's rows
 // (env.py:234-238: world := starting grid); occ_s (the env's LDS occupancy row) may be nullptr when the
@@ -414,10 +557,12 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ inline void glds16(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 16, 0, 0); }
 __device__ inline void glds16_sc1(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 16, 0, 16); }
 __device__ inline void glds4(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 4, 0, 0); }
+__device__ inline void glds4_sc1(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 4, 0, 16); }
 #else
 __device__ inline void glds16(const void*, uint32_t*) {}
 __device__ inline void glds16_sc1(const void*, uint32_t*) {}
 __device__ inline void glds4(const void*, uint32_t*) {}
+__device__ inline void glds4_sc1(const void*, uint32_t*) {}
 #endif
 
 // The LDS-DMA loads of one changed env into scratch slot k (whole wave).  L2: bypass this CU's L1 (the fused
@@ -437,7 +582,10 @@ __device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, i
     s4 -= reinterpret_cast<uintptr_t>(s4) & 3;
     const int8_t* b4 = p.task_meta[rq.task].bbox;
     const int8_t* src = lane < 32 ? t4 + 4 * lane : lane == 32 ? s4 : b4 + 4 * (lane - 33);
-    if (lane < 37) glds4(src, ws.aux[k]);
+    if (lane < 37) {
+        if (L2) glds4_sc1(src, ws.aux[k]);  // the fused rollout may have regenerated this task row earlier in the launch
+        else glds4(src, ws.aux[k]);
+    }
 }
 
 // Publishes the wave's changed envs and starts the DMA for the first chunk.  Returns the ballot of leaders.
@@ -564,10 +712,13 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
     return G.bcast_first(hmax_l);
 }
 
-// auto-reset rows of every done env of this wave (whole wave per env, coalesced)
-template <int GS>
+// auto-reset rows of every done env of this wave (whole wave per env, coalesced).  With the RandomTasks
+// generator on, the env's task row is regenerated first (row_s: 1104 bytes of LDS scratch) and the lanes of
+// the env learn the new target size through `generated_size`.
+template <int GS, bool RT>
 __device__ inline void resolve_resets(const Grp<GS>& G, const KParams& p, bool do_reset, int env, int task,
-                                      bool has_start, uint32_t* occ_wave_s) {
+                                      bool has_start, uint32_t ep, uint32_t* occ_wave_s, int8_t* row_s,
+                                      int& generated_size) {
     uint64_t m = __ballot(do_reset);
     while (m) {
         const int l = __builtin_ctzll(m);
@@ -577,13 +728,62 @@ __device__ inline void resolve_resets(const Grp<GS>& G, const KParams& p, bool d
         else m &= ~(((1ull << GS) - 1ull) << (gsel * GS));
         const int t_env = __builtin_amdgcn_readlane(env, l);
         const int t_task = __builtin_amdgcn_readlane(task, l);
-        const int t_hs = __builtin_amdgcn_readlane((int)has_start, l);
+        int t_hs = __builtin_amdgcn_readlane((int)has_start, l);
+        if constexpr (RT) {
+            if (p.rt_enabled) {
+                const int n = sample_random_task_wave(p, t_env, (uint32_t)__builtin_amdgcn_readlane((int)ep, l), row_s);
+                if (__lane_id() / GS == gsel) generated_size = n;
+                t_hs = 0;
+            }
+        }
         reset_rows_wave(p, t_env, t_task, t_hs != 0, occ_wave_s ? occ_wave_s + gsel * OCC_PITCH : nullptr);
     }
 }
 
-template <int GS, int MODE>
-__global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
+// One IGW_TRAJ_BYTES record of the episode log (include/igw.h) by the env's leader lane; `ep`: the episode the
+// step belongs to.  Actions are re-read from the caller's buffers (nothing is kept in registers for the log).
+template <int MODE>
+__device__ inline void write_trajectory(const KParams& p, const ActIn& a, int env, int task, uint32_t ep, const Env& e,
+                                        const CellChange& ch, const StepOut& o, bool was_reset, int task_next) {
+    int32_t* head = p.traj_heads + ((size_t)env * 2 + (ep & 1)) * 4;
+    const int step = e.step_no;  // 1-based, already counted
+    if (step >= 1 && step <= p.traj_cap) {
+        uint32_t rec[16];
+        rec[0] = __float_as_uint((float)e.x); rec[1] = __float_as_uint((float)e.y); rec[2] = __float_as_uint((float)e.z);
+        rec[3] = __float_as_uint((float)e.pitch); rec[4] = __float_as_uint((float)e.yaw);
+        rec[5] = __float_as_uint((float)o.reward);
+        rec[6] = __float_as_uint((float)(e.yaw - 180.0));
+        rec[7] = ch.idx < 0 ? 0xffffffffu : ((uint32_t)ch.idx | (((uint32_t)ch.new_val & 0xffu) << 16));
+        rec[8] = (uint32_t)(e.inv & 0xffffffffull);
+        rec[9] = (uint32_t)((e.inv >> 32) & 0xffffull) | ((o.done ? 1u : 0u) << 16) | ((uint32_t)MODE << 24);
+        for (int i = 10; i < 16; i++) rec[i] = 0;
+        if (MODE == MODE_WALK) {
+            rec[10] = (uint32_t)a.actions[env];
+        } else if (MODE == MODE_FLY) {
+            for (int i = 0; i < 3; i++) rec[10 + i] = __float_as_uint(a.movement[3 * (size_t)env + i]);
+            for (int i = 0; i < 2; i++) rec[13 + i] = __float_as_uint(a.camera[2 * (size_t)env + i]);
+            rec[15] = ((uint32_t)a.inventory[env] & 0xffu) | (((uint32_t)a.placement[env] & 0xffu) << 8);
+        } else {
+            const uint2 bw = *reinterpret_cast<const uint2*>(a.buttons + 8 * (size_t)env);
+            rec[10] = bw.x; rec[11] = bw.y;
+            for (int i = 0; i < 2; i++) rec[12 + i] = __float_as_uint(a.camera[2 * (size_t)env + i]);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(p.traj + (((size_t)env * 2 + (ep & 1)) * p.traj_cap + (step - 1)) * IGW_TRAJ_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[i] = make_uint4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+    }
+    *reinterpret_cast<int4*>(head) = make_int4(task, min(step, p.traj_cap), (int)ep, o.done ? 1 : 0);
+    if (was_reset)  // the next episode's slot starts empty
+        *reinterpret_cast<int4*>(p.traj_heads + ((size_t)env * 2 + ((ep + 1) & 1)) * 4) = make_int4(task_next, 0, (int)(ep + 1), 0);
+}
+
+// __launch_bounds__(BLOCK, 4): four waves per SIMD, i.e. at most 128 VGPRs -- the whole 65,536-env batch at four
+// lanes per env is then co-resident (4,096 waves = 4 per SIMD) and runs in one round.
+// EXTRA: the RandomTasks generator and the episode log are compiled in (launched only when one of them is enabled,
+// so the plain kernel carries neither their code nor their registers).  Narrow groups pack so many envs per block
+// that LDS (one occupancy row per env) caps them at 2-3 blocks per CU anyway.
+template <int GS, int MODE, bool EXTRA>
+__global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams p, ActIn a) {
     __shared__ BlockShared<GS> sh;
     const Grp<GS> G;
     TrigCtx trig;
@@ -623,17 +823,33 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
             const float* cam = a.camera + 2 * (size_t)env;
             const bool fwd = bw.x & 0xffu, back = bw.x & 0xff00u, left = bw.x & 0xff0000u, right = bw.x & 0xff000000u;
             const bool jump = bw.y & 0xffu, attack = bw.y & 0xff00u, use = bw.y & 0xff0000u;
-            const int hotbar = (int)(bw.y >> 24);
+            int hotbar = (int)(bw.y >> 24);
+            double c0 = (double)cam[0], c1 = (double)cam[1];
+            // the reference raises on these (core/world.py:354-355) or would carry NaN into the pose: run the
+            // offending component as a no-op and count it (IGW_STAT_BAD_ACTION)
+            bool bad = false;
+            if (hotbar > 6) { hotbar = 0; bad = true; }
+            if (!__builtin_isfinite(c0)) { c0 = 0.0; bad = true; }
+            if (!__builtin_isfinite(c1)) { c1 = 0.0; bad = true; }
+            if (bad && G.gl == 0) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
             const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
-            ch = world_act<GS, MODE_WALK_DICT>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar,
-                                               (double)cam[0], (double)cam[1], attack, use, mv);
+            ch = world_act<GS, MODE_WALK_DICT>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
+                                               attack, use, mv);
         } else {  // parse_flying_action, core/world.py:416-432
             const float* mvm = a.movement + 3 * (size_t)env;
             const float* cam = a.camera + 2 * (size_t)env;
             const int placement = a.placement[env];
-            ch = world_act<GS, MODE_FLY>(G, p, e, occ_s, grid_g, trig, (double)mvm[0], (double)mvm[1], (double)mvm[2],
-                                         a.inventory[env], (double)cam[0], (double)cam[1], placement == 2,
-                                         placement == 1, mv);
+            int inventory = a.inventory[env];
+            double f[5] = {(double)mvm[0], (double)mvm[1], (double)mvm[2], (double)cam[0], (double)cam[1]};
+            bool bad = false;  // see the walking Dict branch
+            if ((unsigned)inventory > 6u) { inventory = 0; bad = true; }
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (!__builtin_isfinite(f[i])) { f[i] = 0.0; bad = true; }
+            }
+            if (bad && G.gl == 0) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
+            ch = world_act<GS, MODE_FLY>(G, p, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
+                                         placement == 2, placement == 1, mv);
         }
         // issued here, consumed after the histogram update
         if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
@@ -670,19 +886,20 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     StepOut o;
     o.reward = 0.0; o.done = false;
     bool do_reset = false;
+    uint32_t ep = 0;
+    const int task_old = task;
+    int generated_size = -1;
     if (active) {
         o = finish_step(p, e, env_max_int, size_new, mi);
         do_reset = o.done && p.autoreset;
         if (do_reset) {
-            if (p.sample_tasks) {  // the next episode's task (task generator on the device)
-                task = rng_task(p.sample_seed, (uint64_t)env, (uint64_t)p.tick, p.n_tasks);
-                if (G.gl == 0) p.env_task[env] = task;
-            }
+            ep = next_task(p, env, G.gl == 0, task);  // the next episode's task (task generators on the device)
             meta = p.task_meta + task;
-            has_start = meta->has_start != 0;
+            has_start = !p.rt_enabled && meta->has_start != 0;
         }
     }
-    resolve_resets<GS>(G, p, do_reset, env, task, has_start, nullptr);
+    resolve_resets<GS, EXTRA>(G, p, do_reset, env, task, has_start, ep, nullptr,
+                              reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
 #ifdef IGW_DIAG
     {
         const unsigned long long n_ch = __builtin_popcountll(__ballot(changed && G.gl == 0));
@@ -692,7 +909,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(KParams p, ActIn a) {
     }
 #endif
     if (!active) return;
-    if (do_reset) reset_env_regs(e, meta, false);
+    if constexpr (EXTRA) {
+        if (p.traj && env < p.traj_n && G.gl == 0) {
+            const uint32_t ep_now = do_reset ? ep : __hip_atomic_load(p.episode + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            write_trajectory<MODE>(p, a, env, task_old, ep_now, e, ch, o, do_reset, task);
+        }
+    }
+    if (do_reset) reset_env_regs(e, meta, false, generated_size);
     if (G.gl == 0) {
         if (ch.idx >= 0 && !do_reset) {
             grid_g[ch.idx] = (int8_t)ch.new_val;
@@ -787,19 +1010,21 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
             // colours go to HBM right away (a later break of this launch reads them)
             if (ch.idx >= 0 && !do_reset && G.gl == 0) grid_g[ch.idx] = (int8_t)ch.new_val;
         }
-        if (active && do_reset && p.sample_tasks) {
-            task = rng_task(p.sample_seed, (uint64_t)env, (uint64_t)(p.tick + t), p.n_tasks);
-            if (G.gl == 0) p.env_task[env] = task;
+        uint32_t ep = 0;
+        int generated_size = -1;
+        if (active && do_reset) {
+            ep = next_task(p, env, G.gl == 0, task);
             meta = p.task_meta + task;
-            has_start = meta->has_start != 0;
-            env_max_int = meta->env_max_int;
+            has_start = !p.rt_enabled && meta->has_start != 0;
+            env_max_int = p.rt_enabled ? 0 : meta->env_max_int;
         }
         wave_sync();
-        resolve_resets<GS>(G, p, do_reset, env, task, has_start, occ_wave_s);
+        resolve_resets<GS, true>(G, p, do_reset, env, task, has_start, ep, occ_wave_s,
+                                 reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (active && do_reset) {
-            reset_env_regs(e, meta, false);
+            reset_env_regs(e, meta, false, generated_size);
             n_resets++;
         }
     }
@@ -821,24 +1046,28 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
 
 // GridWorld.reset for the masked envs: one wavefront per env (rows move coalesced)
 __global__ __launch_bounds__(BLOCK) void reset_kernel(KParams p, const uint8_t* mask, int keep_size) {
+    __shared__ alignas(16) int8_t row_s[WAVES_PER_BLOCK][STRIDE];  // RandomTasks generator scratch
     const int env = blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE;
     if (env >= p.n_envs) return;
     if (mask && !mask[env]) return;
     Env e;
     env_load(e, p.agent + env);
     int task = p.env_task[env];
-    if (p.sample_tasks) {
-        task = rng_task(p.sample_seed, (uint64_t)env, (uint64_t)p.tick, p.n_tasks);
-        if (__lane_id() == 0) p.env_task[env] = task;
-    }
+    const uint32_t ep = next_task(p, env, __lane_id() == 0, task);
     const TaskMeta* meta = p.task_meta + task;
-    reset_rows_wave(p, env, task, meta->has_start != 0, nullptr);
-    reset_env_regs(e, meta, keep_size != 0);
+    int generated_size = -1;
+    bool has_start = false;
+    if (p.rt_enabled) generated_size = sample_random_task_wave(p, env, ep, row_s[threadIdx.x / WAVE]);
+    else has_start = meta->has_start != 0;
+    reset_rows_wave(p, env, task, has_start, nullptr);
+    reset_env_regs(e, meta, keep_size != 0, generated_size);
     if (__lane_id() == 0) {
         write_reset_obs(p, env, e);
         p.reward[env] = 0.f;
         p.done[env] = 0;
         env_store(e, p.agent + env);
+        if (p.traj && env < p.traj_n)  // the new episode's slot of the log starts empty
+            *reinterpret_cast<int4*>(p.traj_heads + ((size_t)env * 2 + ((ep + 1) & 1)) * 4) = make_int4(task, 0, (int)(ep + 1), 0);
     }
 }
 
@@ -851,48 +1080,6 @@ __global__ void fill_actions_kernel(int32_t* actions, long long n_envs, long lon
 }
 
 // ---------------------------------------------------------------- Task.__init__ on device
-
-struct BBox {
-    int xmin, xmax, zmin, zmax;
-};
-
-// bounding box of the non-zero cells of an LDS row (wave-wide); empty -> (10, 0, 10, 0)
-__device__ inline BBox row_bbox(const int8_t* row_s, int& nnz) {
-    const int lane = __lane_id();
-    int xmin = 10, xmax = 0, zmin = 10, zmax = 0, cnt = 0;
-    for (int c = lane; c < CELLS; c += WAVE) {
-        if (row_s[c] != 0) {
-            const int r = c % LEVEL, x = r / 11, z = r % 11;
-            xmin = min(xmin, x); xmax = max(xmax, x);
-            zmin = min(zmin, z); zmax = max(zmax, z);
-            cnt++;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    nnz = cnt;
-    BBox b;
-    b.xmin = wave_min_i32(xmin); b.xmax = wave_max_i32(xmax);
-    b.zmin = wave_min_i32(zmin); b.zmax = wave_max_i32(zmax);
-    if (cnt == 0) { b.xmin = 10; b.xmax = 0; b.zmin = 10; b.zmax = 0; }
-    return b;
-}
-
-__device__ inline int pack_bbox(int xmin, int xmax, int zmin, int zmax) {
-    return (xmin & 0xff) | ((xmax & 0xff) << 8) | ((zmin & 0xff) << 16) | ((zmax & 0xff) << 24);
-}
-// bboxes of the 4 rotations (x,z) -> (z, 10-x) (tasks/task.py:52-53) of a box; admissible translations
-// of rotation r are dx in [xmax-10, xmin], dz in [zmax-10, zmin] (tasks/task.py:62-72 as a bbox rule)
-__device__ inline void rot_bboxes(const BBox& b, bool empty, int* out4) {
-    if (empty) {
-        out4[0] = out4[1] = out4[2] = out4[3] = pack_bbox(10, 0, 10, 0);
-        return;
-    }
-    out4[0] = pack_bbox(b.xmin, b.xmax, b.zmin, b.zmax);
-    out4[1] = pack_bbox(b.zmin, b.zmax, 10 - b.xmax, 10 - b.xmin);
-    out4[2] = pack_bbox(10 - b.xmax, 10 - b.xmin, 10 - b.zmax, 10 - b.zmin);
-    out4[3] = pack_bbox(10 - b.zmax, 10 - b.zmin, b.xmin, b.xmax);
-}
 
 struct PrepShared {
     alignas(16) int8_t a[WAVES_PER_BLOCK][STRIDE];  // target / synthetic target
@@ -980,7 +1167,20 @@ __global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int fir
     if (lane == 0) {
         TaskMeta m;
         memset(&m, 0, sizeof(m));
-        for (int k = 0; k < 5; k++) m.pose[k] = init_pose ? init_pose[5 * (size_t)i + k] : 0.0;
+        // initial pose (GridWorld.initialize_world, env.py:177-193).  The ray march and the physics index the world
+        // around the agent without range checks (igw_device.h), which holds for |x|, |z| <= 10: anything else, or a
+        // non-finite value, is replaced by the default pose and counted (IGW_STAT_BAD_POSE)
+        bool pose_ok = true;
+        for (int k = 0; k < 5; k++) {
+            const double v = init_pose ? init_pose[5 * (size_t)i + k] : 0.0;
+            const double lim = (k == 0 || k == 2) ? 10.0 : k == 1 ? 64.0 : 1e6;
+            pose_ok = pose_ok && __builtin_isfinite(v) && __builtin_fabs(v) <= lim;
+            m.pose[k] = v;
+        }
+        if (!pose_ok) {
+            for (int k = 0; k < 5; k++) m.pose[k] = 0.0;
+            stat_add(p.stats, IGW_STAT_BAD_POSE, 1);
+        }
         m.target_size = (int16_t)nnz_t;
         m.env_max_int = (int16_t)r.max_int;
         for (int k = 0; k < 4; k++) {
@@ -1130,6 +1330,7 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     c->kp.max_steps = cfg->max_steps;
     c->kp.autoreset = cfg->autoreset;
     c->kp.debug = cfg->reserved;
+    c->kp.env_base = cfg->env_index_base;
     c->kp.right_scale = cfg->right_placement_scale;
     c->kp.wrong_scale = cfg->wrong_placement_scale;
     {
@@ -1142,11 +1343,61 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
     return IGW_OK;
 }
 
-int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed) {
+int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t n_tasks) {
     if (!ctx) return fail(IGW_ERR_INVALID, "igw_set_task_sampling: null context");
+    if (enabled) {
+        if (!ctx->bound || !ctx->kp.episode) return fail(IGW_ERR_UNBOUND, "igw_set_task_sampling: needs bound buffers with igw_buffers.episode");
+        if (n_tasks > ctx->cfg.num_tasks) return fail(IGW_ERR_INVALID, "igw_set_task_sampling: n_tasks exceeds the task table");
+        if (ctx->kp.rt_enabled) return fail(IGW_ERR_INVALID, "igw_set_task_sampling: the RandomTasks generator is enabled on this context");
+    }
     ctx->kp.sample_tasks = enabled ? 1 : 0;
-    ctx->kp.n_tasks = ctx->cfg.num_tasks;
+    ctx->kp.n_tasks = n_tasks > 0 ? n_tasks : ctx->cfg.num_tasks;
     ctx->kp.sample_seed = seed;
+    return IGW_OK;
+}
+
+int igw_set_random_tasks(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t max_blocks, int32_t height_levels,
+                         int32_t max_dist, int32_t num_colors, void* stream) {
+    if (!ctx) return fail(IGW_ERR_INVALID, "igw_set_random_tasks: null context");
+    if (!enabled) {
+        ctx->kp.rt_enabled = 0;
+        return IGW_OK;
+    }
+    if (!ctx->bound || !ctx->kp.episode) return fail(IGW_ERR_UNBOUND, "igw_set_random_tasks: needs bound buffers with igw_buffers.episode");
+    if (ctx->cfg.num_tasks < ctx->cfg.num_envs) return fail(IGW_ERR_INVALID, "igw_set_random_tasks: needs one task row per env (num_tasks >= num_envs)");
+    if (ctx->kp.sample_tasks) return fail(IGW_ERR_INVALID, "igw_set_random_tasks: task sampling is enabled on this context");
+    if (max_blocks < 1 || height_levels < 1 || height_levels > IGW_GRID_Y || max_dist < 1 || num_colors < 1 || num_colors > 6)
+        return fail(IGW_ERR_INVALID, "igw_set_random_tasks: need max_blocks >= 1, 1 <= height_levels <= 9, max_dist >= 1, 1 <= num_colors <= 6");
+    DeviceGuard guard(ctx->cfg.device);
+    if (!guard.ok) return fail(IGW_ERR_HIP, "igw_set_random_tasks: hipSetDevice failed");
+    // generated tasks have an empty starting grid: the start rows of the envs' own task rows are zeroed once
+    const size_t n = (size_t)ctx->cfg.num_envs;
+    HIP_TRY(hipMemsetAsync(const_cast<int8_t*>(ctx->kp.task_start), 0, n * STRIDE, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(const_cast<uint32_t*>(ctx->kp.task_start_occ), 0, n * OCC_WORDS * sizeof(uint32_t), (hipStream_t)stream));
+    ctx->kp.rt_enabled = 1;
+    ctx->kp.rt_max_blocks = max_blocks;
+    ctx->kp.rt_levels = height_levels;
+    ctx->kp.rt_max_dist = max_dist > 10 ? 10 : max_dist;  // 10 already covers the plane from any first block
+    ctx->kp.rt_colors = num_colors;
+    ctx->kp.sample_seed = seed;
+    return IGW_OK;
+}
+
+int igw_set_trajectory_log(igw_ctx* ctx, void* records, int32_t* heads, int32_t n_logged, int32_t capacity) {
+    if (!ctx) return fail(IGW_ERR_INVALID, "igw_set_trajectory_log: null context");
+    if (!records || !heads || n_logged <= 0) {
+        ctx->kp.traj = nullptr;
+        ctx->kp.traj_heads = nullptr;
+        ctx->kp.traj_n = 0;
+        return IGW_OK;
+    }
+    if (!ctx->bound || !ctx->kp.episode) return fail(IGW_ERR_UNBOUND, "igw_set_trajectory_log: needs bound buffers with igw_buffers.episode");
+    if (n_logged > ctx->cfg.num_envs || capacity < 1) return fail(IGW_ERR_INVALID, "igw_set_trajectory_log: n_logged / capacity out of range");
+    if (((uintptr_t)records | (uintptr_t)heads) & 15) return fail(IGW_ERR_INVALID, "igw_set_trajectory_log: buffers must be 16-byte aligned");
+    ctx->kp.traj = reinterpret_cast<uint8_t*>(records);
+    ctx->kp.traj_heads = heads;
+    ctx->kp.traj_n = n_logged;
+    ctx->kp.traj_cap = capacity;
     return IGW_OK;
 }
 
@@ -1190,6 +1441,10 @@ int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
     k.reward = b->reward;
     k.done = b->done;
     k.stats = reinterpret_cast<unsigned long long*>(b->stats);
+    k.episode = b->episode;
+    if (!k.episode) {  // features keyed by the episode counter cannot outlive it
+        k.sample_tasks = 0; k.rt_enabled = 0; k.traj = nullptr; k.traj_heads = nullptr; k.traj_n = 0;
+    }
     ctx->bound = true;
     return IGW_OK;
 }
@@ -1210,6 +1465,18 @@ int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
         case 2: { constexpr int GS = 2; CALL; } break;   \
         default: { constexpr int GS = 1; CALL; } break;  \
     }
+
+// the step kernel with or without the rarely used extras (RandomTasks generator, episode log)
+#define LAUNCH_STEP(MODE)                                                                                          \
+    do {                                                                                                           \
+        if (ctx->kp.rt_enabled || ctx->kp.traj) {                                                                  \
+            DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE, true>), dim3(env_blocks(ctx)), dim3(BLOCK), 0, \
+                                                    (hipStream_t)stream, ctx->kp, a));                             \
+        } else {                                                                                                   \
+            DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE, false>), dim3(env_blocks(ctx)), dim3(BLOCK), 0, \
+                                                    (hipStream_t)stream, ctx->kp, a));                             \
+        }                                                                                                          \
+    } while (0)
 
 static inline int env_blocks(const igw_ctx* ctx) {
     const int epb = BLOCK / ctx->gs;
@@ -1234,7 +1501,6 @@ int igw_reset(igw_ctx* ctx, const uint8_t* mask, int32_t flags, void* stream) {
     const int keep = (flags & IGW_RESET_KEEP_SIZE) ? 1 : 0;
     const int blocks = (ctx->cfg.num_envs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, ctx->kp, mask, keep);
-    ctx->kp.tick += 1;
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1244,9 +1510,7 @@ int igw_step_walking(igw_ctx* ctx, const int32_t* actions, void* stream) {
     if (ctx->cfg.action_space != IGW_WALKING_DISCRETE) return fail(IGW_ERR_INVALID, "igw_step_walking: context was created for another action space");
     if (!actions) return fail(IGW_ERR_INVALID, "igw_step_walking: actions is null");
     ActIn a = {actions, nullptr, nullptr, nullptr, nullptr, nullptr};
-    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_WALK>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
-                                            (hipStream_t)stream, ctx->kp, a));
-    ctx->kp.tick += 1;
+    LAUNCH_STEP(MODE_WALK);
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1257,9 +1521,7 @@ int igw_step_flying(igw_ctx* ctx, const float* movement, const float* camera, co
     if (ctx->cfg.action_space != IGW_FLYING) return fail(IGW_ERR_INVALID, "igw_step_flying: context was created for another action space");
     if (!movement || !camera || !inventory || !placement) return fail(IGW_ERR_INVALID, "igw_step_flying: an action buffer is null");
     ActIn a = {nullptr, movement, camera, inventory, placement, nullptr};
-    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_FLY>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
-                                            (hipStream_t)stream, ctx->kp, a));
-    ctx->kp.tick += 1;
+    LAUNCH_STEP(MODE_FLY);
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1270,9 +1532,7 @@ int igw_step_walking_dict(igw_ctx* ctx, const uint8_t* buttons, const float* cam
     if (!buttons || !camera) return fail(IGW_ERR_INVALID, "igw_step_walking_dict: an action buffer is null");
     if ((uintptr_t)buttons & 7) return fail(IGW_ERR_INVALID, "igw_step_walking_dict: buttons must be 8-byte aligned");
     ActIn a = {nullptr, nullptr, camera, nullptr, nullptr, buttons};
-    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE_WALK_DICT>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
-                                            (hipStream_t)stream, ctx->kp, a));
-    ctx->kp.tick += 1;
+    LAUNCH_STEP(MODE_WALK_DICT);
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1285,7 +1545,6 @@ int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int6
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(rollout_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, (long long)T, (unsigned long long)seed,
                                             (long long)t0, (long long)env_offset));
-    ctx->kp.tick += T;
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }

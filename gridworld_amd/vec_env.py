@@ -35,7 +35,8 @@ class VecGridWorld:
 
     def __init__(self, num_envs, device='cuda:0', action_space='walking', select_and_place=True,
                  size_reward=True, max_steps=250, right_placement_scale=1., wrong_placement_scale=0.1,
-                 discretize=True, autoreset=False, num_tasks=None, lanes_per_env=0, debug_flags=0, **ignored):
+                 discretize=True, autoreset=False, num_tasks=None, lanes_per_env=0, debug_flags=0, env_index_base=0,
+                 **ignored):
         if not torch.cuda.is_available():
             raise L.IgwError('VecGridWorld needs a HIP device (no CPU fallback)')
         if action_space not in ('walking', 'flying'):
@@ -65,6 +66,7 @@ class VecGridWorld:
         self.reward = z((N,), torch.float32)
         self.done = z((N,), torch.uint8)
         self.stats_buf = z((L.STAT_STRIPES, 8), torch.int64)
+        self.episode = z((N,), torch.int32)  # episodes started per env (keys the device-side task generators)
         # Agent.__init__ (core/world.py:12-29): time_int_steps = 2, active_block = BLUE, inventory 20
         self.agent_buf[:, 56:62] = 20
         self.agent_buf[:, 62] = 1 << 2  # u16 pack: time_int_steps code 0 (= 2), active_block 1, target_size 0
@@ -72,17 +74,22 @@ class VecGridWorld:
                             L.FLYING if self.flying else L.WALKING_DICT if self.walk_dict else L.WALKING_DISCRETE,
                             int(select_and_place), int(size_reward), self.max_steps, int(autoreset),
                             float(right_placement_scale), float(wrong_placement_scale), int(lanes_per_env),
-                            int(debug_flags))
+                            int(debug_flags), int(env_index_base))
+        self.env_index_base = int(env_index_base)
         self.ctx = C.c_void_p()
         L.check(self.lib.igw_create(C.byref(self.cfg), C.byref(self.ctx)), 'igw_create')
         b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.occ_buf, self.hist_buf, self.agent_buf, self.env_task,
                                                 self.task_target, self.task_start, self.task_start_occ, self.task_meta,
                                                 self.agent_pos, self.inventory, self.compass, self.reward, self.done,
-                                                self.stats_buf)])
+                                                self.stats_buf, self.episode)])
         L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(b)), 'igw_bind_buffers')
         self.grid = torch.as_strided(self.grid_buf, (N, 9, 11, 11), (L.GRID_STRIDE, 121, 11, 1))
         self.user_target = None
         self._have_tasks = False
+        self._tasks_filled = 0       # rows of the task table written so far (what task sampling draws from)
+        self._sampling = None        # (seed,) / ('random', kwargs) of the device-side generator, for sub-batches
+        self._traj = None
+        self._children = []
 
     def __del__(self):
         ctx = getattr(self, 'ctx', None)
@@ -106,17 +113,33 @@ class VecGridWorld:
         inv = None
         if invariant is not None:
             inv = torch.as_tensor(np.broadcast_to(np.asarray(invariant, dtype=np.uint8), (T,)).copy(), device=dev)
+        if first < 0 or first + T > self.num_tasks:
+            raise ValueError(f'task rows [{first}, {first + T}) do not fit the table of {self.num_tasks}')
+        for name, g in (('starts', st), ('full_grids', fg)):
+            if g is not None and g.shape[0] != T:
+                raise ValueError(f'{name} has {g.shape[0]} rows, targets {T}')
         pose = None
         if init_pose is not None:
-            pose = torch.as_tensor(np.asarray(init_pose, dtype=np.float64).reshape(T, 5), device=dev).contiguous()
+            pose_np = np.asarray(init_pose, dtype=np.float64).reshape(T, 5)
+            # the kernels index the world around the agent without range checks; that holds for |x|, |z| <= 10
+            # (the C ABI replaces anything else by the default pose and counts it, IGW_STAT_BAD_POSE)
+            ok = np.isfinite(pose_np).all() and (np.abs(pose_np[:, [0, 2]]) <= 10).all() and \
+                (np.abs(pose_np[:, 1]) <= 64).all() and (np.abs(pose_np[:, 3:]) <= 1e6).all()
+            if not ok:
+                raise ValueError('init_pose must be finite with |x|, |z| <= 10, |y| <= 64 and |yaw|, |pitch| <= 1e6')
+            pose = torch.as_tensor(pose_np, device=dev).contiguous()
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
         L.check(self.lib.igw_prepare_tasks(self.ctx, first, T, ptr(tgt), ptr(st), ptr(fg), ptr(inv), ptr(pose),
                                            self._stream()), 'igw_prepare_tasks')
         if self.user_target is None:
             self.user_target = torch.zeros((self.num_tasks, L.GRID_STRIDE), dtype=torch.int8, device=dev)
         self.user_target[first:first + T] = tgt
+        self._tasks_filled = max(self._tasks_filled, first + T)
         if env_task is not None:
-            self.env_task.copy_(torch.as_tensor(env_task, dtype=torch.int32, device=dev))
+            et = np.asarray(env_task.cpu() if torch.is_tensor(env_task) else env_task).reshape(-1)
+            if et.shape[0] != self.num_envs or et.min() < 0 or et.max() >= self.num_tasks:
+                raise ValueError(f'env_task needs {self.num_envs} indices into the task table [0, {self.num_tasks})')
+            self.env_task.copy_(torch.as_tensor(et.astype(np.int32), device=dev))
         elif first == 0:
             if T == self.num_envs:
                 self.env_task.copy_(torch.arange(self.num_envs, dtype=torch.int32, device=dev))
@@ -125,15 +148,61 @@ class VecGridWorld:
         self._keep = (tgt, st, fg, inv, pose)  # keep inputs alive until the async kernel ran
         self._have_tasks = True
 
-    def set_task_sampling(self, enabled=True, seed=0):
-        """Draw every env's task uniformly from the task table at each reset / auto-reset, on the device
-        (CustomTasks.reset semantics; counter RNG keyed by seed, env and the number of launches so far)."""
-        L.check(self.lib.igw_set_task_sampling(self.ctx, int(bool(enabled)), int(seed)), 'igw_set_task_sampling')
+    def set_task_sampling(self, enabled=True, seed=0, n_tasks=None):
+        """Draw every env's task uniformly from the filled rows of the task table at each reset / auto-reset, on
+        the device (CustomTasks.reset semantics; counter RNG keyed by seed, global env index and the env's
+        episode counter, so it also advances inside a replayed HIP graph)."""
+        n = int(n_tasks if n_tasks is not None else self._tasks_filled)
+        if enabled and not 0 < n <= self.num_tasks:
+            raise ValueError('set_task_sampling needs filled task rows: call set_tasks first')
+        L.check(self.lib.igw_set_task_sampling(self.ctx, int(bool(enabled)), int(seed), n), 'igw_set_task_sampling')
+        self._sampling = ('table', int(seed), n) if enabled else None
+        for c in self._children:
+            c._inherit_sampling()
+
+    def set_random_tasks(self, enabled=True, seed=0, max_blocks=4, height_levels=1, max_dist=2, num_colors=1):
+        """RandomTasks(max_blocks, height_levels, max_dist=.., num_colors=..) (gridworld/tasks/task_set.py:59-157)
+        with sample_task() on the device: every reset / auto-reset writes a freshly sampled target into the env's
+        own task row -- no host in the reset path.  Needs num_tasks == num_envs (the default)."""
+        kw = dict(max_blocks=int(max_blocks), height_levels=int(height_levels), max_dist=int(max_dist),
+                  num_colors=int(num_colors))
+        L.check(self.lib.igw_set_random_tasks(self.ctx, int(bool(enabled)), int(seed), kw['max_blocks'],
+                                              kw['height_levels'], kw['max_dist'], kw['num_colors'], self._stream()),
+                'igw_set_random_tasks')
+        self._sampling = ('random', int(seed), kw) if enabled else None
+        if enabled:
+            self._have_tasks = True
+            self._tasks_filled = max(self._tasks_filled, self.num_envs)
+        for c in self._children:
+            c._inherit_sampling()
+
+    def targets(self):
+        """Current synthetic target (target - start) of every env, [N, 9, 11, 11] int8 (a gather from the task table)."""
+        rows = self.task_target[self.env_task.long()]
+        return rows[:, :L.CELLS].reshape(self.num_envs, 9, 11, 11)
+
+    # ---- episode log (the reference's Logged wrapper, gridworld/wrappers.py:66-134, without video) ----
+    def enable_trajectory_log(self, n_envs=1, capacity=None):
+        """The first n_envs envs record every step on the device (one 64-byte record per step, two episode slots
+        per env); see gridworld_amd.wrappers.EpisodeLogger for the npz dumps."""
+        n_envs = int(n_envs)
+        cap = int(capacity or self.max_steps)
+        rec = torch.zeros((n_envs, 2, cap, L.TRAJ_BYTES), dtype=torch.uint8, device=self.device)
+        heads = torch.zeros((n_envs, 2, 4), dtype=torch.int32, device=self.device)
+        L.check(self.lib.igw_set_trajectory_log(self.ctx, rec.data_ptr(), heads.data_ptr(), n_envs, cap),
+                'igw_set_trajectory_log')
+        self._traj = (rec, heads, n_envs, cap)
+        return rec, heads
+
+    def disable_trajectory_log(self):
+        L.check(self.lib.igw_set_trajectory_log(self.ctx, None, None, 0, 0), 'igw_set_trajectory_log')
+        self._traj = None
 
     def state_dict(self):
         """Snapshot of the complete env state (tensors are cloned): resume / parity debugging."""
         keys = ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'env_task', 'task_target', 'task_start',
-                'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass', 'reward', 'done', 'stats_buf')
+                'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass', 'reward', 'done', 'stats_buf',
+                'episode')
         return {k: getattr(self, k).clone() for k in keys}
 
     def load_state_dict(self, state):
@@ -175,6 +244,8 @@ class VecGridWorld:
                 b = torch.stack([torch.as_tensor(np.asarray(actions[k]), device=dev).to(torch.uint8).reshape(-1)
                                  for k in ('forward', 'back', 'left', 'right', 'jump', 'attack', 'use', 'hotbar')],
                                 dim=1).contiguous()
+            if b.shape[0] != self.num_envs:
+                raise ValueError(f'walking Dict action needs {self.num_envs} rows of 8 buttons, got {tuple(b.shape)}')
             cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).reshape(self.num_envs, 2).contiguous()
             L.check(self.lib.igw_step_walking_dict(self.ctx, b.data_ptr(), cam.data_ptr(), self._stream()),
                     'igw_step_walking_dict')
@@ -184,17 +255,24 @@ class VecGridWorld:
             cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).contiguous()
             inv = torch.as_tensor(actions['inventory'], device=dev).to(torch.int32).contiguous()
             pl = torch.as_tensor(actions['placement'], device=dev).to(torch.int32).contiguous()
+            N = self.num_envs
+            if mv.numel() != 3 * N or cam.numel() != 2 * N or inv.numel() != N or pl.numel() != N:
+                raise ValueError(f'flying action needs movement [{N},3], camera [{N},2], inventory [{N}], placement [{N}]')
             L.check(self.lib.igw_step_flying(self.ctx, mv.data_ptr(), cam.data_ptr(), inv.data_ptr(),
                                              pl.data_ptr(), self._stream()), 'igw_step_flying')
             self._act_keep = (mv, cam, inv, pl)
         else:
             a = torch.as_tensor(actions, device=dev).to(torch.int32).contiguous()
+            if a.numel() != self.num_envs:
+                raise ValueError(f'walking action needs {self.num_envs} entries, got {a.numel()}')
             L.check(self.lib.igw_step_walking(self.ctx, a.data_ptr(), self._stream()), 'igw_step_walking')
             self._act_keep = a
         return self.obs(), self.reward, self.done, {}
 
     def step_walking_ptr(self, actions_i32):
         """Hot-loop variant: `actions_i32` is already a contiguous int32 device tensor [N]."""
+        if actions_i32.numel() != self.num_envs:
+            raise ValueError(f'walking action needs {self.num_envs} entries, got {actions_i32.numel()}')
         L.check(self.lib.igw_step_walking(self.ctx, actions_i32.data_ptr(), self._stream()), 'igw_step_walking')
 
     def rollout(self, T, seed, t0=0, env_offset=0):
@@ -214,18 +292,31 @@ class VecGridWorld:
         """`parts` contiguous sub-batches that SHARE this env's tensors (each is a view of rows
         [lo, hi)) but have their own context and HIP stream, so they can be stepped independently --
         e.g. policy inference on one half overlaps env stepping of the other (EnvPool-style async mode).
-        Envs are independent, so results are identical to stepping the whole batch."""
+        Envs are independent, so results are identical to stepping the whole batch.  Every sub-batch stream
+        first waits for the work already queued on the current stream (set_tasks / reset / steps of the parent);
+        SubBatch.synchronize() / join() order the current stream after the sub-batch again."""
         if self.num_envs % parts:
             raise ValueError('num_envs must be divisible by parts')
         n = self.num_envs // parts
         streams = streams or [torch.cuda.Stream(device=self.device) for _ in range(parts)]
-        return [SubBatch(self, k * n, n, streams[k]) for k in range(parts)]
+        cur = torch.cuda.current_stream(self.device)
+        subs = []
+        for k in range(parts):
+            streams[k].wait_stream(cur)
+            subs.append(SubBatch(self, k * n, n, streams[k]))
+        self._children.extend(subs)
+        return subs
 
     # ---- introspection ----
     def stats(self):
-        s = self.stats_buf.sum(0).cpu()
+        """Device counters of this env and of its sub-batches (VecGridWorld.split)."""
+        s = self.stats_buf.sum(0)
+        for c in self._children:
+            s = s + c.stats_buf.sum(0)
+        s = s.cpu()
         return {'changed': int(s[L.STAT_CHANGED]), 'resets': int(s[L.STAT_RESETS]),
-                'rollout_steps': int(s[L.STAT_STEPS]), 'rescans': int(s[L.STAT_RESCANS])}
+                'rollout_steps': int(s[L.STAT_STEPS]), 'rescans': int(s[L.STAT_RESCANS]),
+                'bad_poses': int(s[L.STAT_BAD_POSE]), 'bad_actions': int(s[L.STAT_BAD_ACTION])}
 
     def internals(self):
         """float64 [N,8]: x, y, z, yaw, pitch, dy, time_int_steps, active_block (debug / parity)."""
@@ -247,13 +338,16 @@ class VecGridWorld:
 
 
 class SubBatch:
-    """Rows [lo, lo + n) of a VecGridWorld behind their own igw context and stream (VecGridWorld.split)."""
+    """Rows [lo, lo + n) of a VecGridWorld behind their own igw context and stream (VecGridWorld.split).
+    The context carries the parent's global env offset, so device-side task generators draw the streams the
+    whole batch would draw, and inherits the parent's generator settings."""
 
     def __init__(self, parent, lo, n, stream):
         self.parent, self.lo, self.num_envs, self.stream = parent, lo, n, stream
         self.lib, self.device = parent.lib, parent.device
         cfg = L.Config.from_buffer_copy(parent.cfg)
         cfg.num_envs = n
+        cfg.env_index_base = parent.env_index_base + lo
         self.cfg = cfg
         self.ctx = C.c_void_p()
         L.check(self.lib.igw_create(C.byref(cfg), C.byref(self.ctx)), 'igw_create')
@@ -262,12 +356,23 @@ class SubBatch:
         outs = (parent.agent_pos, parent.inventory, parent.compass, parent.reward, parent.done)
         self.stats_buf = torch.zeros_like(parent.stats_buf)
         ptrs = [t[lo:lo + n].data_ptr() for t in per_env] + [t.data_ptr() for t in shared] + \
-               [t[lo:lo + n].data_ptr() for t in outs] + [self.stats_buf.data_ptr()]
+               [t[lo:lo + n].data_ptr() for t in outs] + [self.stats_buf.data_ptr(), parent.episode[lo:lo + n].data_ptr()]
         L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(L.Buffers(*ptrs))), 'igw_bind_buffers')
         sl = slice(lo, lo + n)
         self.agent_pos, self.inventory = parent.agent_pos[sl], parent.inventory[sl]
         self.compass, self.reward, self.done = parent.compass[sl], parent.reward[sl], parent.done[sl]
         self.grid = parent.grid[sl]
+        self._inherit_sampling()
+
+    def _inherit_sampling(self):
+        sp = self.parent._sampling
+        if sp is None:
+            L.check(self.lib.igw_set_task_sampling(self.ctx, 0, 0, 0), 'igw_set_task_sampling')
+            L.check(self.lib.igw_set_random_tasks(self.ctx, 0, 0, 1, 1, 1, 1, None), 'igw_set_random_tasks')
+        elif sp[0] == 'table':
+            L.check(self.lib.igw_set_task_sampling(self.ctx, 1, sp[1], sp[2]), 'igw_set_task_sampling')
+        else:  # generated rows are indexed by the context's local env, a sub-batch would overwrite rows of another
+            raise L.IgwError('the RandomTasks generator cannot be combined with sub-batches')
 
     def __del__(self):
         if getattr(self, 'ctx', None):
@@ -279,7 +384,11 @@ class SubBatch:
                 'grid': self.grid}
 
     def step_walking_ptr(self, actions_i32):
-        """actions_i32: contiguous int32 device tensor [n]; launched on this sub-batch's stream."""
+        """actions_i32: contiguous int32 device tensor [n]; launched on this sub-batch's stream (the tensor is
+        marked as in use there, so the caching allocator does not recycle it while the kernel reads it)."""
+        if actions_i32.numel() != self.num_envs:
+            raise ValueError(f'walking action needs {self.num_envs} entries, got {actions_i32.numel()}')
+        actions_i32.record_stream(self.stream)
         L.check(self.lib.igw_step_walking(self.ctx, actions_i32.data_ptr(), C.c_void_p(self.stream.cuda_stream)),
                 'igw_step_walking')
 
@@ -289,6 +398,10 @@ class SubBatch:
 
     def synchronize(self):
         self.stream.synchronize()
+
+    def join(self):
+        """Orders the current stream after everything queued on this sub-batch (no host wait)."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
 
 def task_eval(targets, grids, full_grids=None, invariant=None, device='cuda:0'):

@@ -35,3 +35,124 @@ class Actions(Wrapper):
 
     def step(self, action):
         return self.env.step(self.action_map[action])
+
+
+class EpisodeLogger:
+    """Per-episode npz dumps of what the reference's `Logged` wrapper collects (gridworld/wrappers.py:66-134:
+    every observation key stacked over reset + steps, `reward`, `done`, the actions as csv; no video), taken
+    from the trajectory log the step kernels keep on the device (VecGridWorld.enable_trajectory_log,
+    include/igw.h: igw_set_trajectory_log) -- the env loop itself never copies observations to the host.
+
+        log = EpisodeLogger(vec_env, n_envs=4, path='episodes')
+        ... step / reset as usual ...; files = log.collect()      # any time; dumps the episodes that finished
+
+    Arrays per file (T = steps of the episode): agentPos f32[T+1,5], inventory f32[T+1,6], compass f32[T+1,1],
+    grid int32[T+1,9,11,11] (rebuilt from the starting grid and the logged one-cell changes), reward f64[T],
+    done bool[T], plus `task` (row of the task table), `env`, `episode`.  Entry 0 is the reset observation."""
+
+    def __init__(self, vec, n_envs=1, path='episodes', desc='', glob_step=0, capacity=None):
+        import numpy as np
+        self.np = np
+        self.vec, self.path, self.desc, self.glob_step = vec, path, desc, glob_step
+        self.records, self.heads = vec.enable_trajectory_log(n_envs, capacity)
+        self.n_envs = int(n_envs)
+        self._dumped = {}  # env -> last episode number written
+        self.episodes = []  # the dicts that were dumped (also returned by collect)
+
+    def set_path(self, path):
+        self.path = path
+
+    def set_desc(self, desc, glob_step):
+        self.desc, self.glob_step = desc, glob_step
+
+    def _decode(self, env, slot, task, length):
+        np, v = self.np, self.vec
+        from . import _lib as L
+        raw = self.records[env, slot, :length].cpu().numpy()
+        f32 = raw[:, :28].copy().view(np.float32).reshape(length, 7)
+        change = raw[:, 28:32].copy().view(np.int32)[:, 0]
+        meta = v.task_meta[task].cpu().numpy()
+        inv0 = meta[64:70].view(np.int8).astype(np.float32)
+        grid0 = v.task_start[task, :L.CELLS].cpu().numpy().astype(np.int32).reshape(9, 11, 11)
+        grids = np.empty((length + 1, 9, 11, 11), np.int32)
+        grids[0] = grid0
+        for t in range(length):
+            grids[t + 1] = grids[t]
+            if change[t] != -1:
+                grids[t + 1].reshape(-1)[change[t] & 0xffff] = np.int8((change[t] >> 16) & 0xff)
+        space = int(raw[0, 39]) if length else 0
+        if space == 0:
+            actions = raw[:, 40:44].copy().view(np.int32)[:, 0]
+        elif space == 1:
+            actions = {'movement': raw[:, 40:52].copy().view(np.float32).reshape(length, 3),
+                       'camera': raw[:, 52:60].copy().view(np.float32).reshape(length, 2),
+                       'inventory': raw[:, 60].astype(np.int32), 'placement': raw[:, 61].astype(np.int32)}
+        else:
+            actions = {'buttons': raw[:, 40:48].copy(), 'camera': raw[:, 48:56].copy().view(np.float32).reshape(length, 2)}
+        zeros = np.zeros((1, 5), np.float32)
+        return {'agentPos': np.concatenate([zeros, f32[:, :5]]),
+                'inventory': np.concatenate([inv0[None], raw[:, 32:38].astype(np.float32)]),
+                'compass': np.concatenate([np.zeros((1, 1), np.float32), f32[:, 6:7]]),
+                'grid': grids, 'reward': f32[:, 5].astype(np.float64), 'done': raw[:, 38].astype(bool),
+                'actions': actions, 'task': int(task)}
+
+    def collect(self, dump=True):
+        """Decodes (and with dump=True writes) every logged episode that finished since the last call."""
+        import os
+        import uuid
+        np = self.np
+        import torch
+        torch.cuda.synchronize(self.vec.device)
+        heads = self.heads.cpu().numpy()
+        out = []
+        for env in range(self.n_envs):
+            for slot in (0, 1):
+                task, length, episode, finished = (int(x) for x in heads[env, slot])
+                if not finished or length == 0 or self._dumped.get(env, -1) >= episode:
+                    continue
+                ep = self._decode(env, slot, task, length)
+                ep.update(env=env, episode=episode)
+                self._dumped[env] = max(self._dumped.get(env, -1), episode)
+                if dump:
+                    d = f'{self.path}/step{self.glob_step}'
+                    os.makedirs(d, exist_ok=True)
+                    fname = f'{d}/ep_{self.desc}_{uuid.uuid4().hex[:6]}'
+                    arrays = {k: v for k, v in ep.items() if k != 'actions'}
+                    if isinstance(ep['actions'], dict):
+                        arrays.update({'action_' + k: v for k, v in ep['actions'].items()})
+                    np.savez_compressed(fname + '.npz', **arrays)
+                    if not isinstance(ep['actions'], dict):
+                        with open(fname + '.csv', 'w') as f:
+                            for a in ep['actions']:
+                                f.write(f'{int(a)}\n')
+                    ep['file'] = fname + '.npz'
+                out.append(ep)
+        self.episodes.extend(out)
+        return out
+
+
+class Logged(Wrapper):
+    """The reference's Logged wrapper for the 1-env facade (gridworld/wrappers.py:66-134), without the renderer:
+    turn_on() / set_path() / set_desc(); an episode is written when it ends while logging is on."""
+
+    def __init__(self, env):
+        super().__init__(env)
+        self.logging = False
+        self.turned_off = True
+        self._log = EpisodeLogger(env.unwrapped._vec, 1, path='episodes')
+
+    def turn_on(self):
+        self.turned_off = False
+        self.logging = True
+
+    def set_path(self, path):
+        self._log.set_path(path)
+
+    def set_desc(self, desc, glob_step):
+        self._log.set_desc(desc, glob_step)
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        if done:
+            self._log.collect(dump=self.logging)
+        return obs, reward, done, info

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IGW_VERSION 1
+#define IGW_VERSION 2
 /* igw_config.lanes_per_env == 0 picks the widest power-of-two lane group (64 = one wavefront per env ... 1 =
  * one lane per env) that keeps a launch at or below this many wavefronts (4 per SIMD on MI355X), except
  * that 2 is never chosen (4 lanes unlock the lane-split collide and trig).  65,536 envs -> 4 lanes per env. */
@@ -65,6 +65,11 @@ extern "C" {
 #define IGW_STAT_RESETS 1  /* auto-resets performed */
 #define IGW_STAT_STEPS 2   /* env-steps executed by igw_rollout_walking */
 #define IGW_STAT_RESCANS 3 /* histogram row updates (env-steps that changed a cell; each takes the row maximum) */
+#define IGW_STAT_BAD_POSE 4   /* task rows whose init_pose was rejected (non-finite, |x| or |z| > 10, |y| > 64,
+                               * |yaw| or |pitch| > 1e6) and replaced by the default pose */
+#define IGW_STAT_BAD_ACTION 5 /* env-steps whose action was rejected and executed as a no-op component: non-finite
+                               * movement / camera values, inventory / hotbar ids outside 0..6 (the reference
+                               * raises ValueError there, core/world.py:354-355) */
 
 enum igw_status {
     IGW_OK = 0,
@@ -93,7 +98,9 @@ typedef struct igw_config {
     double right_placement_scale; /* env.py:335 */
     double wrong_placement_scale; /* env.py:337 */
     int32_t lanes_per_env;     /* 0 = automatic from num_envs (see IGW_TARGET_WAVES); or 64,32,...,1 */
-    int32_t reserved;          /* must be 0 (timing-only ablation switches for profiling) */
+    int32_t reserved;          /* must be 0 (ablation switches of the IGW_DIAG build) */
+    int64_t env_index_base;    /* global index of env 0 of this context (rank offset, sub-batch offset): keys the
+                                * on-device task samplers so shards and sub-batches draw different streams */
 } igw_config;
 
 /*
@@ -143,6 +150,8 @@ typedef struct igw_buffers {
     float* reward;         /* [N]    (float) of the double reward */
     uint8_t* done;         /* [N] */
     uint64_t* stats;       /* [IGW_STAT_STRIPES][8], caller zeroes; may be NULL */
+    uint32_t* episode;     /* [N] episodes started per env (every reset adds 1); keys the on-device task samplers and
+                            * the trajectory log; may be NULL unless one of those is enabled */
 } igw_buffers;
 
 typedef struct igw_ctx igw_ctx;
@@ -167,10 +176,36 @@ int igw_prepare_tasks(igw_ctx* ctx, int32_t first, int32_t n, const int8_t* user
                       const double* init_pose, void* stream);
 
 /* Task generator on the device (CustomTasks.reset, gridworld/tasks/task_set.py:53-56): when enabled every
- * reset -- igw_reset and the auto-reset inside the step kernels -- first draws env_task uniformly from the
- * task table with a counter RNG keyed by (seed, env, number of launches so far).  Same distribution as the
- * reference's np.random.choice, not the same stream. */
-int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed);
+ * reset -- igw_reset and the auto-reset inside the step kernels -- first draws env_task uniformly from rows
+ * [0, n_tasks) of the task table (n_tasks <= 0: the whole table) with a counter RNG keyed by (seed,
+ * env_index_base + env, episode[env]).  Same distribution as the reference's np.random.choice, not the
+ * same stream; replayable from a HIP graph (the key lives in device memory).  Needs igw_buffers.episode. */
+int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t n_tasks);
+
+/* RandomTasks.sample_task on the device (gridworld/tasks/task_set.py:135-157): when enabled every reset first
+ * writes a freshly sampled target into the env's OWN task row (env_task[env] := env; needs num_tasks >=
+ * num_envs; starting grid empty, the row's init pose is kept): per height level one block uniform over the
+ * 11 x 11 plane, then max_blocks - 1 further blocks on distinct cells within Chebyshev distance max_dist of
+ * it (all of them when fewer are free -- where the reference's rejection loop never ends), colours uniform in
+ * 1..num_colors.  Sequential rejection sampling without replacement = a uniformly random subset, which is what
+ * the kernel draws in parallel (counter RNG keyed as above): same distribution, not the same stream.
+ * Mutually exclusive with igw_set_task_sampling.  Asynchronous on `stream` (zeroes the starting-grid rows). */
+int igw_set_random_tasks(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t max_blocks, int32_t height_levels,
+                         int32_t max_dist, int32_t num_colors, void* stream);
+
+/* Episode log on the device (what the reference's Logged wrapper collects per step, gridworld/wrappers.py:
+ * 89-121, minus video): for envs [0, n_logged) every step writes one IGW_TRAJ_BYTES record at
+ *   records[env][episode[env] & 1][step_no - 1]     (two episodes of `capacity` steps per env, so a finished
+ * episode stays readable while the next one is written; steps beyond capacity are not recorded) and keeps
+ *   heads[env][episode[env] & 1] = { task row, steps recorded, episode number, 0 }  (int32 x 4) current.
+ * Record layout (little endian):
+ *    0 f32 agentPos[5]   20 f32 reward   24 f32 compass   28 i32 change: -1, or cell | (colour & 0xff) << 16
+ *   32 u8 inventory[6]   38 u8 done      39 u8 action space (igw_action_space)
+ *   40 walking: i32 action | flying: f32 movement[3], f32 camera[2] | walking Dict: u8 buttons[8], f32 camera[2]
+ *   60 flying: i8 inventory, i8 placement     62 u16 0
+ * records / heads NULL disables.  Needs igw_buffers.episode. */
+#define IGW_TRAJ_BYTES 64
+int igw_set_trajectory_log(igw_ctx* ctx, void* records, int32_t* heads, int32_t n_logged, int32_t capacity);
 
 #define IGW_RESET_KEEP_SIZE 1 /* GridWorld.reset only (what set_task calls): SizeReward.size survives */
 /* mask: device uint8[N] or NULL (= all envs) */

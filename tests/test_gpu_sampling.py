@@ -188,3 +188,72 @@ def test_shared_and_partially_updated_task_table():
     assert np.array_equal(env.grid.cpu().numpy().reshape(n, -1), ob.grid)
     assert np.array_equal(env.reward.cpu().numpy(), ob.reward)
     assert np.array_equal(env.internals().view(np.uint64), ob.internals().view(np.uint64))
+
+
+def test_sub_batches_inherit_sampling_and_order_after_parent():
+    """split() right after set_tasks / reset with no host synchronisation in between: the sub-batch streams wait
+    for the parent's queued work; with task sampling on, every sub-batch draws exactly what the whole batch
+    draws (global env index in the RNG key), and the parent's stats() include the sub-batch counters."""
+    from gridworld_amd import VecGridWorld, workloads
+    n, T, ntasks = 4096, 90, 13
+    tg = workloads.rt20(ntasks, seed=5)
+
+    def make():
+        env = VecGridWorld(n, num_tasks=ntasks, autoreset=True, size_reward=False, max_steps=20)
+        env.set_tasks(tg.to(env.device), env_task=np.zeros(n, np.int32))
+        env.set_task_sampling(True, seed=77)
+        env.reset()
+        return env
+    whole = make()
+    acts = whole.fill_actions(T, seed=6)
+    for t in range(T):
+        whole.step_walking_ptr(acts[t])
+    parts_env = make()
+    subs = parts_env.split(4)           # no synchronize: the new streams must order themselves after reset()
+    m = n // 4
+    for t in range(T):
+        for k, sb in enumerate(subs):
+            sb.step_walking_ptr(acts[t, k * m:(k + 1) * m])    # a view: recorded on the sub-batch stream
+    for sb in subs:
+        sb.join()
+    torch.cuda.synchronize()
+    assert torch.equal(whole.env_task, parts_env.env_task) and torch.equal(whole.episode, parts_env.episode)
+    assert torch.equal(whole.grid_buf, parts_env.grid_buf) and torch.equal(whole.agent_buf, parts_env.agent_buf)
+    assert len(torch.unique(parts_env.env_task)) == ntasks
+    sw, sp = whole.stats(), parts_env.stats()
+    assert sw['resets'] == sp['resets'] > 0 and sw['changed'] == sp['changed']
+
+
+def test_sampling_advances_inside_a_replayed_graph():
+    """The sampler's key is the env's episode counter in device memory, not a launch argument: replaying a
+    captured step loop keeps drawing new tasks and stays equal to eager stepping."""
+    from gridworld_amd import VecGridWorld, workloads
+    n, K, ntasks = 2048, 25, 9
+    tg = workloads.rt20(ntasks, seed=3)
+
+    def make():
+        env = VecGridWorld(n, num_tasks=ntasks, autoreset=True, size_reward=False, max_steps=10)
+        env.set_tasks(tg.to(env.device), env_task=np.zeros(n, np.int32))
+        env.set_task_sampling(True, seed=1)
+        env.reset()
+        return env
+    eager, graphed = make(), make()
+    acts = eager.fill_actions(K, seed=2)
+    for rep in range(3):
+        for t in range(K):
+            eager.step_walking_ptr(acts[t])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    snap = graphed.state_dict()
+    with torch.cuda.graph(g):
+        for t in range(K):
+            graphed.step_walking_ptr(acts[t])
+    graphed.load_state_dict(snap)
+    seen = []
+    for rep in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        seen.append(graphed.env_task.clone())
+    assert torch.equal(eager.env_task, graphed.env_task) and torch.equal(eager.grid_buf, graphed.grid_buf)
+    assert torch.equal(eager.episode, graphed.episode) and int(graphed.episode.min()) >= 1 + 3 * (K // 10)
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
