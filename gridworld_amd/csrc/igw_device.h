@@ -258,9 +258,7 @@ __device__ inline uint64_t inv_add(uint64_t inv, int i, int d) {
     return (inv & ~(0xffull << sh)) | ((uint64_t)(uint8_t)v << sh);
 }
 
-__device__ inline void env_load(Env& e, const AgentRec* rec) {
-    // every lane reads the same 64 B line (one request per wave)
-    const AgentRec r = *rec;
+__device__ inline void env_unpack(Env& e, const AgentRec& r) {
     e.x = r.x; e.y = r.y; e.z = r.z; e.yaw = r.yaw; e.pitch = r.pitch; e.vy = r.vy;
     e.step_no = r.step_no; e.size = r.size; e.prev_size = r.prev_size & 0x7fff; e.max_int = r.max_int;
     e.dirty = ((uint16_t)r.prev_size >> 15) & 1;
@@ -269,6 +267,11 @@ __device__ inline void env_load(Env& e, const AgentRec* rec) {
     e.tis = code == 0 ? 2 : code == 1 ? 4 : code == 2 ? 8 : 12;
     e.active = (int)((r.inv_pack >> 50) & 7);
     e.target_size = (int)(r.inv_pack >> 53);
+}
+__device__ inline void env_load(Env& e, const AgentRec* rec) {
+    // every lane reads the same 64 B line (one request per wave)
+    const AgentRec r = *rec;
+    env_unpack(e, r);
 }
 __device__ inline void env_store(const Env& e, AgentRec* rec) {
     AgentRec r;

@@ -265,8 +265,11 @@ __device__ inline void write_step_obs(const KParams& p, int env, const Env& e) {
 struct CellChange {
     int idx;  // dense cell index; -1: grid unchanged this step
     int bit;  // the cell's bit in the HBM occupancy row
+    // old_val: the cell's colour before the step as the RAW zero-extended byte of a (possibly still pending) load:
+    // converting it where it is loaded would make the wave wait for the load there; old_colour() does it at the use
     int old_val, new_val;
 };
+__device__ inline int old_colour(const CellChange& ch) { return (int)(int8_t)ch.old_val; }
 
 struct Motion {  // get_motion_vector (core/world.py:163-201): constant over the sub-steps of one step
     double x, y, z;
@@ -366,7 +369,8 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
             const int cell = cell_of(h.bx, h.by, h.bz);
             // colour of the block: the one int8 the physics ever needs (L1-bypassing load: a fused
             // rollout may have written this row earlier in the same launch)
-            ch.old_val = __hip_atomic_load(grid_g + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ch.old_val = (int)__hip_atomic_load(reinterpret_cast<const uint8_t*>(grid_g) + cell, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
             ch.idx = cell;
             ch.bit = occ_bit_hbm(h.bx, h.by, h.bz);
             ch.new_val = 0;
@@ -389,7 +393,7 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
 // remove_block's inventory refund (env.py:146-153 via the on_remove callback), once the colour has arrived
 __device__ inline void finish_break(Env& e, const CellChange& ch) {
     if (ch.idx >= 0 && ch.new_val == 0) {
-        const int texture = ch.old_val;
+        const int texture = old_colour(ch);
         if (texture >= 1 && texture <= 6) e.inv = inv_add(e.inv, texture - 1, 1);
     }
 }
@@ -457,7 +461,7 @@ __device__ inline WalkAct parse_walking_discrete(int action) {
 // (grid - start).  Only one cell can change per step, so the count is updated incrementally.
 __device__ inline int syn_size_delta(const CellChange& ch, int start_val) {
     if (ch.idx < 0) return 0;
-    return ((ch.new_val - start_val) != 0 ? 1 : 0) - ((ch.old_val - start_val) != 0 ? 1 : 0);
+    return ((ch.new_val - start_val) != 0 ? 1 : 0) - ((old_colour(ch) - start_val) != 0 ? 1 : 0);
 }
 
 // part 2 + GridWorld.step tail (env.py:290-296) + SizeReward.step (env.py:325-331)
@@ -521,17 +525,35 @@ __constant__ double IGW_TRIG_LUT_DEV[IGW_LUT_N * 2];
 // LDS cost a block-wide barrier on every launch's critical path for a handful of lookups per step.
 __device__ inline const double* trig_lut() { return IGW_TRIG_LUT_DEV; }
 
-// the wave's EPW contiguous bitmap rows HBM -> LDS (coalesced dwordx4 both ways), plus the constant words
+// The wave's EPW contiguous bitmap rows HBM -> LDS (coalesced dwordx4 both ways), plus the constant words, in two
+// halves: occ_issue only issues the global loads (so the caller can queue every other load of the step behind
+// them and pay ONE memory round trip), occ_commit writes LDS.
 template <int GS>
-__device__ inline void load_occ_wave(const KParams& p, int first_env, uint32_t* occ_wave_s) {
-    constexpr int EPW = WAVE / GS;
-    constexpr int CH = OCC_WORDS / 4;  // 12 chunks of 16 B per env
+struct OccStage {
+    static constexpr int EPW = WAVE / GS;
+    static constexpr int CH = OCC_WORDS / 4;                  // 12 chunks of 16 B per env
+    static constexpr int ITER = (EPW * CH + WAVE - 1) / WAVE;  // 3 at four lanes per env
+    uint4 v[ITER];
+};
+template <int GS>
+__device__ inline void occ_issue(const KParams& p, int first_env, OccStage<GS>& st) {
     const int lane = __lane_id();
-    const int valid = min(EPW, p.n_envs - first_env);
+    const int valid = min(OccStage<GS>::EPW, p.n_envs - first_env);
     const uint4* src = reinterpret_cast<const uint4*>(p.occ + (size_t)first_env * OCC_WORDS);
-    for (int c = lane; c < valid * CH; c += WAVE) {
-        const uint4 v = src[c];
-        *reinterpret_cast<uint4*>(occ_wave_s + (c / CH) * OCC_PITCH + OCC_VAR0 + (c % CH) * 4) = v;
+#pragma unroll
+    for (int i = 0; i < OccStage<GS>::ITER; i++) {
+        const int c = lane + i * WAVE;
+        st.v[i] = c < valid * OccStage<GS>::CH ? src[c] : make_uint4(0, 0, 0, 0);
+    }
+}
+template <int GS>
+__device__ inline void occ_commit(const OccStage<GS>& st, uint32_t* occ_wave_s) {
+    constexpr int EPW = OccStage<GS>::EPW, CH = OccStage<GS>::CH;
+    const int lane = __lane_id();
+#pragma unroll
+    for (int i = 0; i < OccStage<GS>::ITER; i++) {
+        const int c = lane + i * WAVE;
+        if (c < EPW * CH) *reinterpret_cast<uint4*>(occ_wave_s + (c / CH) * OCC_PITCH + OCC_VAR0 + (c % CH) * 4) = st.v[i];
     }
     // constant words: 4 lanes per env, lane part q writes the 16-byte pieces q of the prefix (words 4q..4q+3)
     // and the zero words behind the variable part
@@ -546,6 +568,37 @@ __device__ inline void load_occ_wave(const KParams& p, int first_env, uint32_t* 
         *reinterpret_cast<uint4*>(row + 4 * q) = pre;
         if (q < 2) *reinterpret_cast<uint4*>(row + OCC_VAR0 + OCC_WORDS + 4 * q) = make_uint4(0, 0, 0, 0);
     }
+}
+template <int GS>
+__device__ inline void load_occ_wave(const KParams& p, int first_env, uint32_t* occ_wave_s) {
+    OccStage<GS> st;
+    occ_issue<GS>(p, first_env, st);
+    occ_commit<GS>(st, occ_wave_s);
+}
+
+// the raw action of one env, loaded before anything waits (parsed later)
+struct RawAct {
+    int32_t action;             // walking Discrete(18)
+    uint2 buttons;              // walking Dict
+    float f[5];                 // flying movement[3] + camera[2]; walking Dict camera in f[3], f[4]
+    int32_t inventory, placement;
+};
+template <int MODE>
+__device__ inline RawAct load_action(const ActIn& a, int env) {
+    RawAct r = {};
+    if (MODE == MODE_WALK) {
+        r.action = a.actions[env];
+    } else if (MODE == MODE_WALK_DICT) {
+        r.buttons = *reinterpret_cast<const uint2*>(a.buttons + 8 * (size_t)env);
+        r.f[3] = a.camera[2 * (size_t)env]; r.f[4] = a.camera[2 * (size_t)env + 1];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) r.f[i] = a.movement[3 * (size_t)env + i];
+        r.f[3] = a.camera[2 * (size_t)env]; r.f[4] = a.camera[2 * (size_t)env + 1];
+        r.inventory = a.inventory[env];
+        r.placement = a.placement[env];
+    }
+    return r;
 }
 
 // LDS-DMA destination: the builtin only sets M0 (the wave-uniform LDS base) when it is handed a pointer that
@@ -637,7 +690,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 if (k < cnt) dma_change_inputs<R, L2>(p, ws, k, ws.req[k]);
             }
         }
-        if (mine) ws.req[my_k - base].old_val = ch.old_val;  // the break's colour has arrived by now
+        if (mine) ws.req[my_k - base].old_val = old_colour(ch);  // the break's colour has arrived by now
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // DMA landed
         wave_sync();
         // Three batched phases over all slots, so their LDS round trips overlap instead of chaining per env.
@@ -797,7 +850,10 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
     if (wave_env0 >= p.n_envs) return;
     stamp(p, 0);
-    load_occ_wave<GS>(p, wave_env0, occ_wave_s);
+    // Every load the step needs before it can compute -- occupancy rows, agent record, task index, action -- is
+    // issued before the first wait: one memory round trip.
+    OccStage<GS> occ_in;
+    occ_issue<GS>(p, wave_env0, occ_in);
     Env e = {};
     CellChange ch;
     ch.idx = -1; ch.bit = 0; ch.old_val = ch.new_val = 0;
@@ -807,24 +863,35 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     const TaskMeta* meta = nullptr;
     int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
     [[maybe_unused]] int diag_m = 0;  // IGW_DIAG: sub-steps this env asked for
+    AgentRec rec = {};
+    RawAct ra = {};
     if (active) {
         task = p.env_task[env];
-        env_load(e, p.agent + env);
+        rec = p.agent[env];  // every lane of the group reads the same 64 B line (one request)
+        ra = load_action<MODE>(a, env);
+    }
+    occ_commit<GS>(occ_in, occ_wave_s);
+    if (active) {
+        env_unpack(e, rec);
+        // an episode that reaches max_steps in this step is reset inside the kernel: start its task's metadata
+        // line on its way now (the reset reads it at the end; with a task generator on the next task is not known yet)
+        [[maybe_unused]] int meta_touch = 0;
+        if (p.autoreset && e.step_no + 1 >= p.max_steps && !p.sample_tasks && !p.rt_enabled)
+            meta_touch = p.task_meta[task].target_size;
         wave_sync();
         stamp(p, 1);
         diag_m = e.tis;
         e.step_no = min(e.step_no + 1, 65535);  // env.py:276
         if (MODE == MODE_WALK) {
-            const WalkAct w = parse_walking_discrete(a.actions[env]);
+            const WalkAct w = parse_walking_discrete(ra.action);
             ch = world_act<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
                                           w.remove, w.add, mv);
         } else if (MODE == MODE_WALK_DICT) {  // parse_walking_action, core/world.py:396-414
-            const uint2 bw = *reinterpret_cast<const uint2*>(a.buttons + 8 * (size_t)env);
-            const float* cam = a.camera + 2 * (size_t)env;
+            const uint2 bw = ra.buttons;
             const bool fwd = bw.x & 0xffu, back = bw.x & 0xff00u, left = bw.x & 0xff0000u, right = bw.x & 0xff000000u;
             const bool jump = bw.y & 0xffu, attack = bw.y & 0xff00u, use = bw.y & 0xff0000u;
             int hotbar = (int)(bw.y >> 24);
-            double c0 = (double)cam[0], c1 = (double)cam[1];
+            double c0 = (double)ra.f[3], c1 = (double)ra.f[4];
             // the reference raises on these (core/world.py:354-355) or would carry NaN into the pose: run the
             // offending component as a no-op and count it (IGW_STAT_BAD_ACTION)
             bool bad = false;
@@ -836,11 +903,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
             ch = world_act<GS, MODE_WALK_DICT>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
                                                attack, use, mv);
         } else {  // parse_flying_action, core/world.py:416-432
-            const float* mvm = a.movement + 3 * (size_t)env;
-            const float* cam = a.camera + 2 * (size_t)env;
-            const int placement = a.placement[env];
-            int inventory = a.inventory[env];
-            double f[5] = {(double)mvm[0], (double)mvm[1], (double)mvm[2], (double)cam[0], (double)cam[1]};
+            const int placement = ra.placement;
+            int inventory = ra.inventory;
+            double f[5] = {(double)ra.f[0], (double)ra.f[1], (double)ra.f[2], (double)ra.f[3], (double)ra.f[4]};
             bool bad = false;  // see the walking Dict branch
             if ((unsigned)inventory > 6u) { inventory = 0; bad = true; }
 #pragma unroll
