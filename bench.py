@@ -62,6 +62,8 @@ def parse_args(argv=None):
                     help='skip the episode de-synchronisation (round-1 behaviour: all envs at the same episode step)')
     ap.add_argument('--mode', choices=['walking', 'flying'], default='walking',
                     help='walking = BASELINE configs[2] (headline); flying = configs[3]')
+    ap.add_argument('--debug-flags', type=int, default=0,
+                    help='IGW_DIAG=1 only: timing-only ablation switches of the diagnostic library (results invalid)')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous check without a GPU: ranks reduce fake counters over gloo')
     return ap.parse_args(argv)
@@ -205,7 +207,7 @@ def main():
 
     flying = args.mode == 'flying'
     env = VecGridWorld(N, device=device, action_space=args.mode, size_reward=False, max_steps=MAX_STEPS,
-                       autoreset=True, lanes_per_env=args.lanes_per_env)
+                       autoreset=True, lanes_per_env=args.lanes_per_env, debug_flags=args.debug_flags)
     env.set_tasks(workloads.rt20(N, seed=args.seed + rank, device=device))
     env.reset()
     g = torch.Generator(device=device)

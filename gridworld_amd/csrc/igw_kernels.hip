@@ -46,7 +46,9 @@ struct StepOut {
 #define IGW_DIAG_FLAG(p, bit) ((p).debug & (bit))
 __device__ inline void stamp(const KParams& p, int slot) {
     if (p.stamps) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // debug bit 8: do not drain -- the stamp then marks when the wave REACHES this point, with the loads of
+        // earlier phases still in flight exactly as in the production kernel
+        if (!(p.debug & 8)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         if (__lane_id() == 0) p.stamps[((size_t)blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE) * 8 + slot] = t;
     }
@@ -496,9 +498,6 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int,
 // touches LDS only: votes are LDS atomics on the staged row, the new maximum is a reduction over the row
 // (always exact: no rescan path), and only the 16-byte pieces that changed go back to HBM.
 
-struct ChangeReq {
-    int env, task, cell, old_val, new_val;
-};
 // changed envs handled together per pass (one 1 KB LDS row each).  Groups of 4+ lanes rarely see more than
 // four changes in a wave; narrow groups pack many envs per wave and pay LDS for their occupancy rows.
 template <int GS>
@@ -508,7 +507,6 @@ template <int R>
 struct WaveScratch {
     alignas(16) uint32_t hist[R][HIST_ROW / 2];
     alignas(16) uint32_t aux[R][AUX_WORDS];
-    ChangeReq req[R];
 };
 
 template <int GS>
@@ -621,19 +619,19 @@ __device__ inline void glds4_sc1(const void*, uint32_t*) {}
 // The LDS-DMA loads of one changed env into scratch slot k (whole wave).  L2: bypass this CU's L1 (the fused
 // rollout re-reads rows it stored earlier in the same launch).
 template <int R, bool L2>
-__device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, int k, const ChangeReq& rq) {
+__device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, int k, int env, int task, int cell) {
     const int lane = __lane_id();
-    const char* hrow = reinterpret_cast<const char*>(p.hist + (size_t)rq.env * HIST_ROW) + 16 * lane;
+    const char* hrow = reinterpret_cast<const char*>(p.hist + (size_t)env * HIST_ROW) + 16 * lane;
     if (L2) glds16_sc1(hrow, ws.hist[k]);  // cache policy sc1
     else glds16(hrow, ws.hist[k]);
     // lanes 0-31: the 128 bytes from the dword holding the first byte of the target level (a level is 121
     // bytes at an arbitrary offset of the 16-byte aligned, 1104-byte row: never leaves the row);
     // lane 32: the dword with the starting grid's byte of the cell; lanes 33-36: the four bounding boxes
-    const int8_t* t4 = p.task_target + (size_t)rq.task * STRIDE + (rq.cell / LEVEL) * LEVEL;
+    const int8_t* t4 = p.task_target + (size_t)task * STRIDE + (cell / LEVEL) * LEVEL;
     t4 -= reinterpret_cast<uintptr_t>(t4) & 3;
-    const int8_t* s4 = p.task_start + (size_t)rq.task * STRIDE + rq.cell;
+    const int8_t* s4 = p.task_start + (size_t)task * STRIDE + cell;
     s4 -= reinterpret_cast<uintptr_t>(s4) & 3;
-    const int8_t* b4 = p.task_meta[rq.task].bbox;
+    const int8_t* b4 = p.task_meta[task].bbox;
     const int8_t* src = lane < 32 ? t4 + 4 * lane : lane == 32 ? s4 : b4 + 4 * (lane - 33);
     if (lane < 37) {
         if (L2) glds4_sc1(src, ws.aux[k]);  // the fused rollout may have regenerated this task row earlier in the launch
@@ -641,83 +639,86 @@ __device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, i
     }
 }
 
-// Publishes the wave's changed envs and starts the DMA for the first chunk.  Returns the ballot of leaders.
+// The wave's changed envs are named by their leader lanes (a ballot); their parameters travel as wave-uniform
+// values (v_readlane of the leader), not through LDS.
+__device__ inline int next_leader(uint64_t& m) {
+    const int l = __builtin_ctzll(m);
+    m &= m - 1;
+    return l;
+}
+
+// Starts the DMA for the first chunk of changed envs.  Returns the ballot of leaders.
 template <int GS, bool L2>
 __device__ inline uint64_t prefetch_changes(const Grp<GS>& G, const KParams& p, WaveScratch<req_chunk<GS>()>& ws,
                                             bool changed, int env, int task, const CellChange& ch) {
     constexpr int R = req_chunk<GS>();
-    const bool leader = changed && G.gl == 0;
-    const uint64_t mask = __ballot(leader);
-    if (mask == 0) return 0;
-    const int my_k = __builtin_popcountll(mask & ((1ull << __lane_id()) - 1ull));
-    if (leader && my_k < R) {
-        ChangeReq& r = ws.req[my_k];
-        r.env = env; r.task = task; r.cell = ch.idx; r.old_val = 0; r.new_val = ch.new_val;
-    }
-    wave_sync();
-    const int cnt = min(R, __builtin_popcountll(mask));
+    const uint64_t mask = __ballot(changed && G.gl == 0);
+    uint64_t m = mask;
 #pragma unroll
     for (int k = 0; k < R; k++) {
-        if (k < cnt) dma_change_inputs<R, L2>(p, ws, k, ws.req[k]);
+        if (m) {
+            const int l = next_leader(m);
+            dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
+                                     __builtin_amdgcn_readlane(ch.idx, l));
+        }
     }
     return mask;
 }
 
 // Applies the changes (after the DMA landed) and returns, per changed env, the new maximum of its histogram.
+// Per chunk of up to R envs: LDS reads of the staged target level / start byte / bounding boxes; votes as LDS
+// atomics that return the word they changed, so every voting lane also stores its new 16-bit count straight
+// to the HBM row (each bin has at most one voter); one read of the updated LDS row per env for the maximum.
 template <int GS, bool L2>
 __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveScratch<req_chunk<GS>()>& ws,
-                                      uint64_t mask, bool changed, int env, int task, const CellChange& ch) {
+                                      uint64_t mask, int env, int task, const CellChange& ch) {
     constexpr int R = req_chunk<GS>();
     if (mask == 0) return 0;
     const int lane = __lane_id();
-    const bool leader = changed && G.gl == 0;
     const int E = __builtin_popcountll(mask);
-    const int my_k = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
     const bool v1 = lane + 64 < LEVEL;
+    const int oldc = old_colour(ch);  // the break's colour has arrived by now
     int hmax_l = 0;
+    uint64_t m = mask;
     for (int base = 0; base < E; base += R) {
         const int cnt = min(R, E - base);
-        const bool mine = leader && my_k >= base && my_k < base + cnt;
-        if (base > 0) {  // more changed envs than scratch rows: fetch the next chunk now (rare)
-            wave_sync();
-            if (mine) {
-                ChangeReq& r = ws.req[my_k - base];
-                r.env = env; r.task = task; r.cell = ch.idx; r.new_val = ch.new_val;
-            }
-            wave_sync();
+        int ll[R], r_env[R], r_task[R], r_cell[R], r_new[R], r_old[R];
 #pragma unroll
-            for (int k = 0; k < R; k++) {
-                if (k < cnt) dma_change_inputs<R, L2>(p, ws, k, ws.req[k]);
+        for (int k = 0; k < R; k++) {
+            ll[k] = 0; r_env[k] = 0; r_task[k] = 0; r_cell[k] = 0; r_new[k] = 0; r_old[k] = 0;
+            if (k < cnt) {
+                const int l = next_leader(m);
+                ll[k] = l;
+                r_env[k] = __builtin_amdgcn_readlane(env, l);
+                r_task[k] = __builtin_amdgcn_readlane(task, l);
+                r_cell[k] = __builtin_amdgcn_readlane(ch.idx, l);
+                r_new[k] = __builtin_amdgcn_readlane(ch.new_val, l);
+                r_old[k] = __builtin_amdgcn_readlane(oldc, l);
+                // more changed envs than scratch rows: the later chunks are fetched only now (rare)
+                if (base > 0) dma_change_inputs<R, L2>(p, ws, k, r_env[k], r_task[k], r_cell[k]);
             }
         }
-        if (mine) ws.req[my_k - base].old_val = old_colour(ch);  // the break's colour has arrived by now
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // DMA landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA landed
         wave_sync();
-        // Three batched phases over all slots, so their LDS round trips overlap instead of chaining per env.
-        // Slots beyond cnt hold stale but in-bounds data; they are read and ignored.
-        ChangeReq rq[R];
-        uint4 before[R];
         int tv0[R], tv1[R], sv[R], bbq[R][4];
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            rq[k] = ws.req[k];
-            before[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+            if (k < cnt) {
+                const int8_t* trow = p.task_target + (size_t)r_task[k] * STRIDE + (r_cell[k] / LEVEL) * LEVEL;
+                const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) + (reinterpret_cast<uintptr_t>(trow) & 3);
+                tv0[k] = tb[lane];
+                tv1[k] = v1 ? tb[lane + 64] : 0;
+                sv[k] = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)r_task[k] * STRIDE + r_cell[k]) & 3];
 #pragma unroll
-            for (int q = 0; q < 4; q++) bbq[k][q] = (int)ws.aux[k][33 + q];
-        }
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            const int8_t* trow = p.task_target + (size_t)rq[k].task * STRIDE + (rq[k].cell / LEVEL) * LEVEL;
-            const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) + (reinterpret_cast<uintptr_t>(trow) & 3);
-            tv0[k] = tb[lane];
-            tv1[k] = v1 ? tb[lane + 64] : 0;
-            sv[k] = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)rq[k].task * STRIDE + rq[k].cell) & 3];
+                for (int q = 0; q < 4; q++) bbq[k][q] = (int)ws.aux[k][33 + q];
+            }
         }
 #pragma unroll
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
-                const int a = rq[k].old_val - sv[k], b = rq[k].new_val - sv[k];  // synthetic grid = grid - start
-                const int rem = rq[k].cell % LEVEL, gx = rem / 11, gz = rem % 11;
+                const int a = r_old[k] - sv[k], b = r_new[k] - sv[k];  // synthetic grid = grid - start
+                const int rem = r_cell[k] % LEVEL, gx = rem / 11, gz = rem % 11;
+                uint16_t* grow = p.hist + (size_t)r_env[k] * HIST_ROW;
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     const int tval = half ? tv1[k] : tv0[k];
@@ -736,8 +737,10 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                             const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
                             if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (task.py:62-72)
                                 const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
-                                const uint32_t one = 1u << (16 * (bin & 1));
-                                atomicAdd(&ws.hist[k][bin >> 1], inc ? one : 0u - one);
+                                const int sh = 16 * (bin & 1);
+                                const uint32_t delta = inc ? (1u << sh) : 0u - (1u << sh);
+                                const uint32_t prev = atomicAdd(&ws.hist[k][bin >> 1], delta);
+                                grow[bin] = (uint16_t)((prev + delta) >> sh);
                             }
                         }
                     }
@@ -745,24 +748,20 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
             }
         }
         wave_sync();
-        uint4 now[R];
-#pragma unroll
-        for (int k = 0; k < R; k++) now[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
 #pragma unroll
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
-                if (now[k].x != before[k].x || now[k].y != before[k].y || now[k].z != before[k].z || now[k].w != before[k].w)
-                    reinterpret_cast<uint4*>(p.hist + (size_t)rq[k].env * HIST_ROW)[lane] = now[k];
-                const uint32_t m01 = max(max(now[k].x & 0xffff, now[k].x >> 16), max(now[k].y & 0xffff, now[k].y >> 16));
-                const uint32_t m23 = max(max(now[k].z & 0xffff, now[k].z >> 16), max(now[k].w & 0xffff, now[k].w >> 16));
+                const uint4 now = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+                const uint32_t m01 = max(max(now.x & 0xffff, now.x >> 16), max(now.y & 0xffff, now.y >> 16));
+                const uint32_t m23 = max(max(now.z & 0xffff, now.z >> 16), max(now.w & 0xffff, now.w >> 16));
                 const int best = wave_max_nonneg((int)max(m01, m23));
-                if (mine && my_k - base == k) hmax_l = best;
+                if (lane / GS == ll[k] / GS) hmax_l = best;
             }
         }
     }
     // a fused rollout reads the rows again in its next step: let the stores reach L2 first
     if (L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return G.bcast_first(hmax_l);
+    return hmax_l;
 }
 
 // auto-reset rows of every done env of this wave (whole wave per env, coalesced).  With the RandomTasks
@@ -852,8 +851,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     stamp(p, 0);
     // Every load the step needs before it can compute -- occupancy rows, agent record, task index, action -- is
     // issued before the first wait: one memory round trip.
-    OccStage<GS> occ_in;
-    occ_issue<GS>(p, wave_env0, occ_in);
+    OccStage<GS> occ_in = {};
+    if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(p, wave_env0, occ_in);  // diag 32: what the occupancy rows cost in the load burst
     Env e = {};
     CellChange ch;
     ch.idx = -1; ch.bit = 0; ch.old_val = ch.new_val = 0;
@@ -932,7 +931,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     }
     stamp(p, 3);
     stamp(p, 4);
-    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, changed, env, task, ch);
+    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env, task, ch);
     size_new = e.prev_size;
     if (active && ch.idx >= 0) {
         size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
@@ -986,10 +985,12 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
             grid_g[ch.idx] = (int8_t)ch.new_val;
             p.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = occ_s[OCC_VAR0 + (ch.bit >> 5)];
         }
-        p.reward[env] = (float)o.reward;
-        p.done[env] = o.done ? 1 : 0;
-        if (do_reset) write_reset_obs(p, env, e);
-        else write_step_obs(p, env, e);
+        if (!IGW_DIAG_FLAG(p, 16)) {  // diag 16: what the output stores cost
+            p.reward[env] = (float)o.reward;
+            p.done[env] = o.done ? 1 : 0;
+            if (do_reset) write_reset_obs(p, env, e);
+            else write_step_obs(p, env, e);
+        }
         env_store(e, p.agent + env);
         if (need) stat_add(p.stats, IGW_STAT_CHANGED, 1);
         if (ch.idx >= 0) stat_add(p.stats, IGW_STAT_RESCANS, 1);
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
             world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
             finish_break(e, ch);
         }
-        const int hmax = resolve_changes<GS, true>(G, p, sh.ws[wave], chg_mask, changed, env, task, ch);
+        const int hmax = resolve_changes<GS, true>(G, p, sh.ws[wave], chg_mask, env, task, ch);
         if (active) {
             size_new = e.prev_size + syn_size_delta(ch, start_val);
             need = size_new != e.prev_size;

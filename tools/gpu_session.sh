@@ -12,6 +12,7 @@ timeout 600 python3 bench.py > $D/bench_default.json 2> $D/bench_default.err
 timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $D/bench_20.json 2> $D/bench_20.err
 timeout 300 python3 bench.py --mode flying --no-cpu-baseline > $D/bench_flying.json 2> $D/bench_flying.err
 timeout 300 python3 tools/stamp_phases.py $D/stamps.npz 4 > $D/stamps.txt 2>&1
+timeout 300 python3 tools/stamp_phases.py $D/stamps_nodrain.npz 4 8 > $D/stamps_nodrain.txt 2>&1
 if [ "$MODE" = "full" ]; then
   timeout 300 python3 bench.py --lanes-per-env 1 --envs-per-gpu 1048576 --steps 50 --no-cpu-baseline --no-fused > $D/bench_1m.json 2> $D/bench_1m.err
   timeout 300 python3 bench.py --lanes-per-env 2 --no-cpu-baseline --no-fused > $D/bench_gs2.json 2> $D/bench_gs2.err
@@ -31,3 +32,4 @@ except Exception as e:
 PY
 done
 head -12 $D/stamps.txt
+head -24 $D/stamps_nodrain.txt

@@ -17,7 +17,8 @@ from gridworld_amd import VecGridWorld, workloads  # noqa: E402
 N = 65536
 out = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/stamps.npz'
 gs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-env = VecGridWorld(N, size_reward=False, autoreset=True, lanes_per_env=gs)
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 8: stamps do not drain the memory queues
+env = VecGridWorld(N, size_reward=False, autoreset=True, lanes_per_env=gs, debug_flags=flags)
 env.set_tasks(workloads.rt20(N, seed=0, device=env.device))
 env.reset()
 g = torch.Generator(device=env.device)
@@ -48,7 +49,7 @@ life = t[:, :, 6] - t[:, :, 0]
 span = t[:, :, 6].max(1) - t[:, :, 0].min(1)
 names = ['loads', 'action + hit_test', 'physics', 'world_step tail', 'histogram update', 'rescan/finish/stores']
 d = np.diff(t, axis=2)
-print(f'lanes/env {gs}: {waves} waves, {a.shape[0]} launches; shader cycles')
+print(f'lanes/env {gs}: {waves} waves, {a.shape[0]} launches; shader cycles; debug flags {flags}')
 print(f'  first start -> last end: mean {span.mean():.0f}   start spread {np.mean(t[:, :, 0].max(1) - t[:, :, 0].min(1)):.0f}')
 print(f'  wave lifetime: mean {life.mean():.0f} p50 {np.percentile(life, 50):.0f} p90 {np.percentile(life, 90):.0f} '
       f'p99 {np.percentile(life, 99):.0f} max(mean over launches) {life.max(1).mean():.0f}')
