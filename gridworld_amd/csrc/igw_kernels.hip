@@ -666,9 +666,10 @@ __device__ inline uint64_t prefetch_changes(const Grp<GS>& G, const KParams& p, 
 }
 
 // Applies the changes (after the DMA landed) and returns, per changed env, the new maximum of its histogram.
-// Per chunk of up to R envs: LDS reads of the staged target level / start byte / bounding boxes; votes as LDS
-// atomics that return the word they changed, so every voting lane also stores its new 16-bit count straight
-// to the HBM row (each bin has at most one voter); one read of the updated LDS row per env for the maximum.
+// Per chunk of up to R envs, three batched phases (their LDS round trips overlap over the envs): reads of the
+// staged row piece / target level / start byte / bounding boxes; votes as LDS atomics without return (they
+// pipeline); one read of the updated row per env for the maximum and the write-back of the 16-byte pieces
+// that changed.
 template <int GS, bool L2>
 __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveScratch<req_chunk<GS>()>& ws,
                                       uint64_t mask, int env, int task, const CellChange& ch) {
@@ -701,9 +702,11 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA landed
         wave_sync();
         int tv0[R], tv1[R], sv[R], bbq[R][4];
+        uint4 before[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
+                before[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
                 const int8_t* trow = p.task_target + (size_t)r_task[k] * STRIDE + (r_cell[k] / LEVEL) * LEVEL;
                 const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) + (reinterpret_cast<uintptr_t>(trow) & 3);
                 tv0[k] = tb[lane];
@@ -718,7 +721,6 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
             if (k < cnt) {
                 const int a = r_old[k] - sv[k], b = r_new[k] - sv[k];  // synthetic grid = grid - start
                 const int rem = r_cell[k] % LEVEL, gx = rem / 11, gz = rem % 11;
-                uint16_t* grow = p.hist + (size_t)r_env[k] * HIST_ROW;
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     const int tval = half ? tv1[k] : tv0[k];
@@ -737,10 +739,8 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                             const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
                             if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (task.py:62-72)
                                 const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
-                                const int sh = 16 * (bin & 1);
-                                const uint32_t delta = inc ? (1u << sh) : 0u - (1u << sh);
-                                const uint32_t prev = atomicAdd(&ws.hist[k][bin >> 1], delta);
-                                grow[bin] = (uint16_t)((prev + delta) >> sh);
+                                const uint32_t one = 1u << (16 * (bin & 1));
+                                atomicAdd(&ws.hist[k][bin >> 1], inc ? one : 0u - one);
                             }
                         }
                     }
@@ -752,6 +752,8 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
                 const uint4 now = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+                if (now.x != before[k].x || now.y != before[k].y || now.z != before[k].z || now.w != before[k].w)
+                    reinterpret_cast<uint4*>(p.hist + (size_t)r_env[k] * HIST_ROW)[lane] = now;
                 const uint32_t m01 = max(max(now.x & 0xffff, now.x >> 16), max(now.y & 0xffff, now.y >> 16));
                 const uint32_t m23 = max(max(now.z & 0xffff, now.z >> 16), max(now.w & 0xffff, now.w >> 16));
                 const int best = wave_max_nonneg((int)max(m01, m23));
