@@ -273,14 +273,25 @@ __device__ inline void env_load(Env& e, const AgentRec* rec) {
     const AgentRec r = *rec;
     env_unpack(e, r);
 }
-__device__ inline void env_store(const Env& e, AgentRec* rec) {
-    AgentRec r;
-    r.x = e.x; r.y = e.y; r.z = e.z; r.yaw = e.yaw; r.pitch = e.pitch; r.vy = e.vy;
-    r.step_no = (uint16_t)e.step_no; r.size = (int16_t)e.size;
-    r.prev_size = (int16_t)(uint16_t)((e.prev_size & 0x7fff) | (e.dirty << 15)); r.max_int = (int16_t)e.max_int;
+// The record is stored in two parts: the pose (bytes 0..47) is final as soon as the physics has run, the
+// counters (bytes 48..63) only after the reward tail.
+__device__ inline void env_store_pose(const Env& e, AgentRec* rec) {
+    double2* d = reinterpret_cast<double2*>(rec);
+    d[0] = make_double2(e.x, e.y);
+    d[1] = make_double2(e.z, e.yaw);
+    d[2] = make_double2(e.pitch, e.vy);
+}
+__device__ inline void env_store_counters(const Env& e, AgentRec* rec) {
+    const uint64_t lo = (uint64_t)(uint16_t)e.step_no | ((uint64_t)(uint16_t)(int16_t)e.size << 16) |
+                        ((uint64_t)(uint16_t)((e.prev_size & 0x7fff) | (e.dirty << 15)) << 32) |
+                        ((uint64_t)(uint16_t)(int16_t)e.max_int << 48);
     const uint64_t code = e.tis == 2 ? 0 : e.tis == 4 ? 1 : e.tis == 8 ? 2 : 3;
-    r.inv_pack = e.inv | (code << 48) | ((uint64_t)(e.active & 7) << 50) | ((uint64_t)(e.target_size & 0x7ff) << 53);
-    *rec = r;
+    const uint64_t hi = e.inv | (code << 48) | ((uint64_t)(e.active & 7) << 50) | ((uint64_t)(e.target_size & 0x7ff) << 53);
+    reinterpret_cast<ulonglong2*>(rec)[3] = make_ulonglong2(lo, hi);
+}
+__device__ inline void env_store(const Env& e, AgentRec* rec) {
+    env_store_pose(e, rec);
+    env_store_counters(e, rec);
 }
 
 // ---------------------------------------------------------------- world queries

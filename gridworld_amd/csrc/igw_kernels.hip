@@ -930,6 +930,13 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         if (MODE == MODE_FLY) world_update<GS, MODE_FLY>(G, p, e, occ_s, mv);
         else world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
         finish_break(e, ch);
+        // Pose, inventory and the grid cell are final now: their stores are issued here, in the shadow of the
+        // histogram update's LDS round trips, not at the very end of the wave.  (A reset at the end of this
+        // step overwrites them -- same lane, same addresses, program order.)
+        if (G.gl == 0) {
+            if (!IGW_DIAG_FLAG(p, 16)) write_step_obs(p, env, e);
+            env_store_pose(e, p.agent + env);
+        }
     }
     stamp(p, 3);
     stamp(p, 4);
@@ -991,9 +998,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
             p.reward[env] = (float)o.reward;
             p.done[env] = o.done ? 1 : 0;
             if (do_reset) write_reset_obs(p, env, e);
-            else write_step_obs(p, env, e);
         }
-        env_store(e, p.agent + env);
+        if (do_reset) env_store_pose(e, p.agent + env);
+        env_store_counters(e, p.agent + env);
         if (need) stat_add(p.stats, IGW_STAT_CHANGED, 1);
         if (ch.idx >= 0) stat_add(p.stats, IGW_STAT_RESCANS, 1);
         if (do_reset) stat_add(p.stats, IGW_STAT_RESETS, 1);
