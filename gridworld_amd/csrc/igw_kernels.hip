@@ -311,7 +311,8 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
     if (strafing) {  // math.degrees(math.atan2(*agent.strafe)), :176
         if (!FLY && s1 == 0.0) strafe_deg = s0 < 0.0 ? -90.0 : 90.0;       // degrees(atan2(-+1, 0))
         else if (!FLY && s0 == 0.0) strafe_deg = s1 < 0.0 ? 180.0 : 0.0;   // degrees(atan2(0, -+1))
-        else strafe_deg = igw_atan2(s0, s1) * D180_OVER_PI;
+        else if constexpr (MODE != MODE_WALK) strafe_deg = igw_atan2(s0, s1) * D180_OVER_PI;
+        // (Discrete(18) moves along one axis at a time: the two cases above are all it can produce)
     }
     const bool want_pitch = want_sight || (FLY && strafing);
     double sp = 0.0, cp = 1.0, sy = 0.0, cy = 1.0, sx = 0.0, cx = 1.0;
@@ -443,19 +444,21 @@ struct WalkAct {
     bool remove, add;
 };
 __device__ inline WalkAct parse_walking_discrete(int action) {
-    WalkAct w = {0.0, 0.0, 0.0, 0.0, 0.0, 0, false, false};
-    if (action == 1) w.s0 = -1.0;
-    else if (action == 2) w.s0 = 1.0;
-    else if (action == 3) w.s1 = -1.0;
-    else if (action == 4) w.s1 = 1.0;
-    else if (action == 5) w.dy = 1.0;
-    else if (action >= 6 && action <= 11) w.inventory = action - 5;
-    else if (action == 12) w.cam0 = -5.0;
-    else if (action == 13) w.cam0 = 5.0;
-    else if (action == 14) w.cam1 = -5.0;
-    else if (action == 15) w.cam1 = 5.0;
-    else if (action == 16) w.remove = true;
-    else if (action == 17) w.add = true;
+    // 1 fwd (s0 = -1), 2 back (+1), 3 left (s1 = -1), 4 right (+1), 5 jump, 6..11 hotbar 1..6, 12 / 13 yaw -+ 5,
+    // 14 / 15 pitch -+ 5, 16 break, 17 place; anything else is a no-op.  Written as selects: the 16 envs of a
+    // wave disagree on the action, so an if-chain only buys exec-mask bookkeeping.
+    const int a = action;
+    const int twice = 2 * a;
+    const auto pair = [&](int lo, int centre) { return (unsigned)(a - lo) < 2u ? twice - centre : 0; };
+    WalkAct w;
+    w.s0 = (double)pair(1, 3);             // 1 -> -1, 2 -> +1
+    w.s1 = (double)pair(3, 7);             // 3 -> -1, 4 -> +1
+    w.cam0 = (double)(5 * pair(12, 25));   // 12 -> -5, 13 -> +5
+    w.cam1 = (double)(5 * pair(14, 29));   // 14 -> -5, 15 -> +5
+    w.dy = a == 5 ? 1.0 : 0.0;
+    w.inventory = (unsigned)(a - 6) < 6u ? a - 5 : 0;
+    w.remove = a == 16;
+    w.add = a == 17;
     return w;
 }
 
@@ -523,55 +526,51 @@ __constant__ double IGW_TRIG_LUT_DEV[IGW_LUT_N * 2];
 // LDS cost a block-wide barrier on every launch's critical path for a handful of lookups per step.
 __device__ inline const double* trig_lut() { return IGW_TRIG_LUT_DEV; }
 
-// The wave's EPW contiguous bitmap rows HBM -> LDS (coalesced dwordx4 both ways), plus the constant words, in two
-// halves: occ_issue only issues the global loads (so the caller can queue every other load of the step behind
-// them and pay ONE memory round trip), occ_commit writes LDS.
+// An env's bitmap row HBM -> LDS by the lanes of its group (lane j moves the 16-byte chunks j, j + GS, ...: a
+// group reads 16 * GS contiguous bytes per instruction), plus the constant words, in two halves: occ_issue only
+// issues the global loads (so the caller can queue every other load of the step behind them and pay ONE
+// memory round trip), occ_commit writes LDS.
 template <int GS>
 struct OccStage {
-    static constexpr int EPW = WAVE / GS;
-    static constexpr int CH = OCC_WORDS / 4;                  // 12 chunks of 16 B per env
-    static constexpr int ITER = (EPW * CH + WAVE - 1) / WAVE;  // 3 at four lanes per env
+    static constexpr int CH = OCC_WORDS / 4;              // 12 chunks of 16 B per env
+    static constexpr int ITER = (CH + GS - 1) / GS;       // 3 at four lanes per env
     uint4 v[ITER];
 };
 template <int GS>
-__device__ inline void occ_issue(const KParams& p, int first_env, OccStage<GS>& st) {
-    const int lane = __lane_id();
-    const int valid = min(OccStage<GS>::EPW, p.n_envs - first_env);
-    const uint4* src = reinterpret_cast<const uint4*>(p.occ + (size_t)first_env * OCC_WORDS);
+__device__ inline void occ_issue(const KParams& p, const Grp<GS>& G, int env, OccStage<GS>& st) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.occ + (size_t)env * OCC_WORDS);
 #pragma unroll
     for (int i = 0; i < OccStage<GS>::ITER; i++) {
-        const int c = lane + i * WAVE;
-        st.v[i] = c < valid * OccStage<GS>::CH ? src[c] : make_uint4(0, 0, 0, 0);
+        const int c = G.gl + i * GS;
+        st.v[i] = (OccStage<GS>::CH % GS == 0 || c < OccStage<GS>::CH) ? src[c] : make_uint4(0, 0, 0, 0);
     }
 }
 template <int GS>
-__device__ inline void occ_commit(const OccStage<GS>& st, uint32_t* occ_wave_s) {
-    constexpr int EPW = OccStage<GS>::EPW, CH = OccStage<GS>::CH;
-    const int lane = __lane_id();
+__device__ inline void occ_commit(const Grp<GS>& G, const OccStage<GS>& st, uint32_t* occ_s, uint32_t* occ_wave_s) {
+    constexpr int CH = OccStage<GS>::CH, EPW = WAVE / GS;
 #pragma unroll
     for (int i = 0; i < OccStage<GS>::ITER; i++) {
-        const int c = lane + i * WAVE;
-        if (c < EPW * CH) *reinterpret_cast<uint4*>(occ_wave_s + (c / CH) * OCC_PITCH + OCC_VAR0 + (c % CH) * 4) = st.v[i];
+        const int c = G.gl + i * GS;
+        if (CH % GS == 0 || c < CH) *reinterpret_cast<uint4*>(occ_s + OCC_VAR0 + 4 * c) = st.v[i];
     }
     // constant words: 4 lanes per env, lane part q writes the 16-byte pieces q of the prefix (words 4q..4q+3)
     // and the zero words behind the variable part
+    const int lane = __lane_id();
     const int q = lane & 3;
     const uint4 pre = q == 0 ? make_uint4(occ_const_word(0), occ_const_word(1), occ_const_word(2), occ_const_word(3))
                     : q == 1 ? make_uint4(occ_const_word(4), occ_const_word(5), occ_const_word(6), occ_const_word(7))
                     : q == 2 ? make_uint4(occ_const_word(8), occ_const_word(9), occ_const_word(10), occ_const_word(11))
                              : make_uint4(occ_const_word(12), occ_const_word(13), occ_const_word(14), occ_const_word(15));
     static_assert(OCC_VAR0 == 16 && OCC_PITCH - OCC_VAR0 - OCC_WORDS == 8, "constant words are written as 4 + 2 pieces of 16 bytes");
-    for (int i = lane >> 2; i < EPW; i += WAVE / 4) {
-        uint32_t* row = occ_wave_s + i * OCC_PITCH;
-        *reinterpret_cast<uint4*>(row + 4 * q) = pre;
-        if (q < 2) *reinterpret_cast<uint4*>(row + OCC_VAR0 + OCC_WORDS + 4 * q) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i0 = 0; i0 < EPW; i0 += WAVE / 4) {
+        const int i = i0 + (lane >> 2);
+        if (EPW >= WAVE / 4 || i < EPW) {
+            uint32_t* row = occ_wave_s + i * OCC_PITCH;
+            *reinterpret_cast<uint4*>(row + 4 * q) = pre;
+            if (q < 2) *reinterpret_cast<uint4*>(row + OCC_VAR0 + OCC_WORDS + 4 * q) = make_uint4(0, 0, 0, 0);
+        }
     }
-}
-template <int GS>
-__device__ inline void load_occ_wave(const KParams& p, int first_env, uint32_t* occ_wave_s) {
-    OccStage<GS> st;
-    occ_issue<GS>(p, first_env, st);
-    occ_commit<GS>(st, occ_wave_s);
 }
 
 // the raw action of one env, loaded before anything waits (parsed later)
@@ -851,101 +850,90 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
     if (wave_env0 >= p.n_envs) return;
     stamp(p, 0);
-    // Every load the step needs before it can compute -- occupancy rows, agent record, task index, action -- is
+    // Lanes past the last env (only in the last wave, when N is not a multiple of the envs per wave) run on a copy
+    // of the last env and store nothing: the step below has no "is this lane alive" control flow.
+    const int env_r = active ? env : p.n_envs - 1;
+    const bool writer = active && G.gl == 0;
+    // Every load the step needs before it can compute -- occupancy row, agent record, task index, action -- is
     // issued before the first wait: one memory round trip.
     OccStage<GS> occ_in = {};
-    if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(p, wave_env0, occ_in);  // diag 32: what the occupancy rows cost in the load burst
-    Env e = {};
+    if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(p, G, env_r, occ_in);  // diag 32: what the occupancy rows cost in the load burst
+    int8_t* grid_g = p.grid + (size_t)env_r * STRIDE;
+    int task = p.env_task[env_r];
+    const AgentRec rec = p.agent[env_r];  // every lane of the group reads the same 64 B line (one request)
+    const RawAct ra = load_action<MODE>(a, env_r);
+    occ_commit<GS>(G, occ_in, occ_s, occ_wave_s);
+    Env e;
+    env_unpack(e, rec);
+    // an episode that reaches max_steps in this step is reset inside the kernel: start its task's metadata
+    // line on its way now (the reset reads it at the end; with a task generator on the next task is not known yet)
+    [[maybe_unused]] int meta_touch = 0;
+    if (p.autoreset && e.step_no + 1 >= p.max_steps && !p.sample_tasks && !p.rt_enabled)
+        meta_touch = p.task_meta[task].target_size;
+    wave_sync();
+    stamp(p, 1);
+    [[maybe_unused]] const int diag_m = e.tis;  // IGW_DIAG: sub-steps this env asked for
+    e.step_no = min(e.step_no + 1, 65535);  // env.py:276
     CellChange ch;
-    ch.idx = -1; ch.bit = 0; ch.old_val = ch.new_val = 0;
-    Motion mv = {0.0, 0.0, 0.0};
-    int size_new = 0, task = 0, env_max_int = 0, start_val = 0;
-    bool need = false, has_start = false;
-    const TaskMeta* meta = nullptr;
-    int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
-    [[maybe_unused]] int diag_m = 0;  // IGW_DIAG: sub-steps this env asked for
-    AgentRec rec = {};
-    RawAct ra = {};
-    if (active) {
-        task = p.env_task[env];
-        rec = p.agent[env];  // every lane of the group reads the same 64 B line (one request)
-        ra = load_action<MODE>(a, env);
-    }
-    occ_commit<GS>(occ_in, occ_wave_s);
-    if (active) {
-        env_unpack(e, rec);
-        // an episode that reaches max_steps in this step is reset inside the kernel: start its task's metadata
-        // line on its way now (the reset reads it at the end; with a task generator on the next task is not known yet)
-        [[maybe_unused]] int meta_touch = 0;
-        if (p.autoreset && e.step_no + 1 >= p.max_steps && !p.sample_tasks && !p.rt_enabled)
-            meta_touch = p.task_meta[task].target_size;
-        wave_sync();
-        stamp(p, 1);
-        diag_m = e.tis;
-        e.step_no = min(e.step_no + 1, 65535);  // env.py:276
-        if (MODE == MODE_WALK) {
-            const WalkAct w = parse_walking_discrete(ra.action);
-            ch = world_act<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
-                                          w.remove, w.add, mv);
-        } else if (MODE == MODE_WALK_DICT) {  // parse_walking_action, core/world.py:396-414
-            const uint2 bw = ra.buttons;
-            const bool fwd = bw.x & 0xffu, back = bw.x & 0xff00u, left = bw.x & 0xff0000u, right = bw.x & 0xff000000u;
-            const bool jump = bw.y & 0xffu, attack = bw.y & 0xff00u, use = bw.y & 0xff0000u;
-            int hotbar = (int)(bw.y >> 24);
-            double c0 = (double)ra.f[3], c1 = (double)ra.f[4];
-            // the reference raises on these (core/world.py:354-355) or would carry NaN into the pose: run the
-            // offending component as a no-op and count it (IGW_STAT_BAD_ACTION)
-            bool bad = false;
-            if (hotbar > 6) { hotbar = 0; bad = true; }
-            if (!__builtin_isfinite(c0)) { c0 = 0.0; bad = true; }
-            if (!__builtin_isfinite(c1)) { c1 = 0.0; bad = true; }
-            if (bad && G.gl == 0) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
-            const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
-            ch = world_act<GS, MODE_WALK_DICT>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
-                                               attack, use, mv);
-        } else {  // parse_flying_action, core/world.py:416-432
-            const int placement = ra.placement;
-            int inventory = ra.inventory;
-            double f[5] = {(double)ra.f[0], (double)ra.f[1], (double)ra.f[2], (double)ra.f[3], (double)ra.f[4]};
-            bool bad = false;  // see the walking Dict branch
-            if ((unsigned)inventory > 6u) { inventory = 0; bad = true; }
+    Motion mv;
+    if (MODE == MODE_WALK) {
+        const WalkAct w = parse_walking_discrete(ra.action);
+        ch = world_act<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
+                                      w.remove, w.add, mv);
+    } else if (MODE == MODE_WALK_DICT) {  // parse_walking_action, core/world.py:396-414
+        const uint2 bw = ra.buttons;
+        const bool fwd = bw.x & 0xffu, back = bw.x & 0xff00u, left = bw.x & 0xff0000u, right = bw.x & 0xff000000u;
+        const bool jump = bw.y & 0xffu, attack = bw.y & 0xff00u, use = bw.y & 0xff0000u;
+        int hotbar = (int)(bw.y >> 24);
+        double c0 = (double)ra.f[3], c1 = (double)ra.f[4];
+        // the reference raises on these (core/world.py:354-355) or would carry NaN into the pose: run the
+        // offending component as a no-op and count it (IGW_STAT_BAD_ACTION)
+        bool bad = false;
+        if (hotbar > 6) { hotbar = 0; bad = true; }
+        if (!__builtin_isfinite(c0)) { c0 = 0.0; bad = true; }
+        if (!__builtin_isfinite(c1)) { c1 = 0.0; bad = true; }
+        if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
+        const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
+        ch = world_act<GS, MODE_WALK_DICT>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
+                                           attack, use, mv);
+    } else {  // parse_flying_action, core/world.py:416-432
+        const int placement = ra.placement;
+        int inventory = ra.inventory;
+        double f[5] = {(double)ra.f[0], (double)ra.f[1], (double)ra.f[2], (double)ra.f[3], (double)ra.f[4]};
+        bool bad = false;  // see the walking Dict branch
+        if ((unsigned)inventory > 6u) { inventory = 0; bad = true; }
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
-                if (!__builtin_isfinite(f[i])) { f[i] = 0.0; bad = true; }
-            }
-            if (bad && G.gl == 0) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
-            ch = world_act<GS, MODE_FLY>(G, p, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
-                                         placement == 2, placement == 1, mv);
+        for (int i = 0; i < 5; i++) {
+            if (!__builtin_isfinite(f[i])) { f[i] = 0.0; bad = true; }
         }
-        // issued here, consumed after the histogram update
-        if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
-        if (p.size_reward && e.step_no == 1) env_max_int = p.task_meta[task].env_max_int;
+        if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
+        ch = world_act<GS, MODE_FLY>(G, p, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
+                                     placement == 2, placement == 1, mv);
     }
+    // issued here, consumed after the histogram update
+    int start_val = 0, env_max_int = 0;
+    if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
+    if (p.size_reward && e.step_no == 1) env_max_int = p.task_meta[task].env_max_int;
     stamp(p, 2);
     const bool changed = active && ch.idx >= 0 && !IGW_DIAG_FLAG(p, 1);
     // the histogram row, target level, start byte and bounding boxes of every changed env start moving into
     // LDS now and land while the physics runs
-    const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env, task, ch);
-    if (active) {
-        if (MODE == MODE_FLY) world_update<GS, MODE_FLY>(G, p, e, occ_s, mv);
-        else world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
-        finish_break(e, ch);
-        // Pose, inventory and the grid cell are final now: their stores are issued here, in the shadow of the
-        // histogram update's LDS round trips, not at the very end of the wave.  (A reset at the end of this
-        // step overwrites them -- same lane, same addresses, program order.)
-        if (G.gl == 0) {
-            if (!IGW_DIAG_FLAG(p, 16)) write_step_obs(p, env, e);
-            env_store_pose(e, p.agent + env);
-        }
+    const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env_r, task, ch);
+    if (MODE == MODE_FLY) world_update<GS, MODE_FLY>(G, p, e, occ_s, mv);
+    else world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
+    finish_break(e, ch);
+    // Pose, inventory and the grid cell are final now: their stores are issued here, in the shadow of the
+    // histogram update's LDS round trips, not at the very end of the wave.  (A reset at the end of this
+    // step overwrites them -- same lane, same addresses, program order.)
+    if (writer) {
+        if (!IGW_DIAG_FLAG(p, 16)) write_step_obs(p, env, e);
+        env_store_pose(e, p.agent + env);
     }
     stamp(p, 3);
     stamp(p, 4);
-    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env, task, ch);
-    size_new = e.prev_size;
-    if (active && ch.idx >= 0) {
-        size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
-        need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
-    }
+    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch);
+    const int size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
+    const bool need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
     int mi = e.max_int;
     if (changed) {
         if (need) {  // max_int = maximal_intersection(grid)
@@ -956,20 +944,17 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         }
     }
     stamp(p, 5);
-    StepOut o;
-    o.reward = 0.0; o.done = false;
-    bool do_reset = false;
+    const StepOut o = finish_step(p, e, env_max_int, size_new, mi);
+    const bool do_reset = active && o.done && p.autoreset;
     uint32_t ep = 0;
     const int task_old = task;
     int generated_size = -1;
-    if (active) {
-        o = finish_step(p, e, env_max_int, size_new, mi);
-        do_reset = o.done && p.autoreset;
-        if (do_reset) {
-            ep = next_task(p, env, G.gl == 0, task);  // the next episode's task (task generators on the device)
-            meta = p.task_meta + task;
-            has_start = !p.rt_enabled && meta->has_start != 0;
-        }
+    bool has_start = false;
+    const TaskMeta* meta = nullptr;
+    if (do_reset) {
+        ep = next_task(p, env, G.gl == 0, task);  // the next episode's task (task generators on the device)
+        meta = p.task_meta + task;
+        has_start = !p.rt_enabled && meta->has_start != 0;
     }
     resolve_resets<GS, EXTRA>(G, p, do_reset, env, task, has_start, ep, nullptr,
                               reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
@@ -1024,7 +1009,11 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
     uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
     if (wave_env0 >= p.n_envs) return;
-    load_occ_wave<GS>(p, wave_env0, occ_wave_s);
+    {
+        OccStage<GS> st;
+        occ_issue<GS>(p, G, active ? env : p.n_envs - 1, st);
+        occ_commit<GS>(G, st, occ_s, occ_wave_s);
+    }
     Env e = {};
     int task = 0, env_max_int = 0;
     bool has_start = false;
