@@ -358,10 +358,12 @@ __device__ inline int rint_i32(double x) {
 
 // x / 5 exactly as IEEE division rounds it, in 3 flops instead of a full f64 division sequence:
 // q0 = RN(x * RN(1/5)), r = x - 5 q0 (exact in an fma), q = RN(q0 + r * RN(1/5)) is the correctly rounded
-// quotient (Markstein's theorem; checked bit-for-bit against x / 5.0 on 4*10^8 arguments).  Zeros and
-// values near the underflow range (where the residual may be inexact) take the real division.
+// quotient (Markstein's theorem; checked bit-for-bit against x / 5.0 on 4*10^8 arguments).  Values near the
+// underflow range (where the residual may be inexact) take the real division.
 __device__ inline double div5(double x) {
-    if (__builtin_fabs(x) >= 0x1p-900) {
+    // zero takes the fast path too: it yields a zero, and the sign of a zero step cannot change any sample
+    // (p + -0 == p + +0 for every p but -0, and normalize(+-0) == 0 either way)
+    if (__builtin_fabs(x) >= 0x1p-900 || x == 0.0) {
         const double c = 0x1.999999999999ap-3;
         const double q = x * c;
         const double r = __builtin_fma(-5.0, q, x);

@@ -698,7 +698,9 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 if (base > 0) dma_change_inputs<R, L2>(p, ws, k, r_env[k], r_task[k], r_cell[k]);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA landed
+        // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks
+        // and the fused rollout wait here
+        if (L2 || base > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         int tv0[R], tv1[R], sv[R], bbq[R][4];
         uint4 before[R];
@@ -922,14 +924,17 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     if (MODE == MODE_FLY) world_update<GS, MODE_FLY>(G, p, e, occ_s, mv);
     else world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
     finish_break(e, ch);
-    // Pose, inventory and the grid cell are final now: their stores are issued here, in the shadow of the
-    // histogram update's LDS round trips, not at the very end of the wave.  (A reset at the end of this
-    // step overwrites them -- same lane, same addresses, program order.)
+    stamp(p, 3);
+    // Everything fetched early (break colour, start byte, the DMA of the changed envs) has to be in by now; the
+    // physics had the time of its sub-steps to cover it.
+    if (chg_mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Pose and observations are final: their stores are issued here -- behind that wait, so it does not wait for
+    // them -- and complete in the shadow of the histogram update's LDS round trips, not at the very end of the
+    // wave.  (A reset at the end of this step overwrites them: same lane, same addresses, program order.)
     if (writer) {
         if (!IGW_DIAG_FLAG(p, 16)) write_step_obs(p, env, e);
         env_store_pose(e, p.agent + env);
     }
-    stamp(p, 3);
     stamp(p, 4);
     const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch);
     const int size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
