@@ -505,11 +505,13 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int,
 // four changes in a wave; narrow groups pack many envs per wave and pay LDS for their occupancy rows.
 template <int GS>
 constexpr int req_chunk() { return GS >= 4 ? 4 : GS == 2 ? 2 : 1; }
+constexpr int ITEMS_MAX = 128;  // >= 121: the matches of one changed env always fit
 constexpr int AUX_WORDS = 40;  // 32 dwords of target level + 1 dword with the start byte + 4 dwords of bounding boxes
 template <int R>
 struct WaveScratch {
     alignas(16) uint32_t hist[R][HIST_ROW / 2];
     alignas(16) uint32_t aux[R][AUX_WORDS];
+    uint32_t items[ITEMS_MAX];  // compacted (target cell, changed env) matches of one chunk, see resolve_changes
 };
 
 template <int GS>
@@ -702,7 +704,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         // and the fused rollout wait here
         if (L2 || base > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
-        int tv0[R], tv1[R], sv[R], bbq[R][4];
+        int tv0[R], tv1[R], sv[R];
         uint4 before[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
@@ -713,41 +715,63 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 tv0[k] = tb[lane];
                 tv1[k] = v1 ? tb[lane + 64] : 0;
                 sv[k] = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)r_task[k] * STRIDE + r_cell[k]) & 3];
-#pragma unroll
-                for (int q = 0; q < 4; q++) bbq[k][q] = (int)ws.aux[k][33 + q];
             }
         }
+        // Votes.  A target cell of the changed cell's level votes when its colour equals the cell's old synthetic
+        // colour (the pair stops matching: -1) or its new one (+1).  Only a handful of the 121 cells do, so the
+        // matches of the whole chunk are first compacted into a list -- every matching lane appends one word:
+        // cell | inc << 7 | slot << 8 | gx << 10 | gz << 14 -- and then four lanes take one match each, one lane
+        // per rotation: the rotation arithmetic runs once per chunk, not once per env and half-level.
+        int n_items = 0;  // wave-uniform
+        const auto vote = [&]() {  // the listed matches vote; four lanes per match, one per rotation
+            wave_sync();
+            for (int i0 = 0; i0 < n_items; i0 += WAVE / 4) {
+                const int it = i0 + (lane >> 2);
+                if (it < n_items) {
+                    const uint32_t w = ws.items[it];
+                    const int q = lane & 3, j = (int)(w & 0x7f), k = (int)((w >> 8) & 3);
+                    const bool inc = (w & 0x80u) != 0;
+                    const int gx = (int)((w >> 10) & 15), gz = (int)((w >> 14) & 15);
+                    const int bb = (int)ws.aux[k][33 + q];
+                    const int tx = j / 11, tz = j % 11;
+                    // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
+                    const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
+                    const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
+                    const int xmin = (int8_t)(bb & 0xff), xmax = (int8_t)((bb >> 8) & 0xff);
+                    const int zmin = (int8_t)((bb >> 16) & 0xff), zmax = (int8_t)((bb >> 24) & 0xff);
+                    const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
+                    if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (task.py:62-72)
+                        const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
+                        const uint32_t one = 1u << (16 * (bin & 1));
+                        atomicAdd(&ws.hist[k][bin >> 1], inc ? one : 0u - one);
+                    }
+                }
+            }
+            wave_sync();
+            n_items = 0;
+        };
 #pragma unroll
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
                 const int a = r_old[k] - sv[k], b = r_new[k] - sv[k];  // synthetic grid = grid - start
                 const int rem = r_cell[k] % LEVEL, gx = rem / 11, gz = rem % 11;
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const int tval = half ? tv1[k] : tv0[k];
-                    const int j = lane + 64 * half;
-                    const bool dec = tval != 0 && tval == a;
-                    const bool inc = tval != 0 && tval == b;
-                    if (dec != inc) {  // (a cell that matched before and after cannot exist: a != b)
-                        const int tx = j / 11, tz = j % 11;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
-                            const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
-                            const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
-                            const int xmin = (int8_t)(bbq[k][q] & 0xff), xmax = (int8_t)((bbq[k][q] >> 8) & 0xff);
-                            const int zmin = (int8_t)((bbq[k][q] >> 16) & 0xff), zmax = (int8_t)((bbq[k][q] >> 24) & 0xff);
-                            const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
-                            if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (task.py:62-72)
-                                const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
-                                const uint32_t one = 1u << (16 * (bin & 1));
-                                atomicAdd(&ws.hist[k][bin >> 1], inc ? one : 0u - one);
-                            }
-                        }
-                    }
+                const uint32_t tag = ((uint32_t)k << 8) | ((uint32_t)gx << 10) | ((uint32_t)gz << 14);
+                // (a cell that matched before and after cannot exist: a != b)
+                const bool dec0 = tv0[k] != 0 && tv0[k] == a, inc0 = tv0[k] != 0 && tv0[k] == b;
+                const bool dec1 = tv1[k] != 0 && tv1[k] == a, inc1 = tv1[k] != 0 && tv1[k] == b;
+                const uint64_t m0 = __ballot(dec0 != inc0), m1 = __ballot(dec1 != inc1);
+                const int c0 = __builtin_popcountll(m0), c1 = __builtin_popcountll(m1);
+                if (c0 + c1) {
+                    if (n_items + c0 + c1 > ITEMS_MAX) vote();  // (a level full of one colour: 121 matches)
+                    const int r0 = n_items + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+                    const int r1 = n_items + c0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+                    if (dec0 != inc0) ws.items[r0] = (uint32_t)lane | (inc0 ? 0x80u : 0u) | tag;
+                    if (dec1 != inc1) ws.items[r1] = (uint32_t)(lane + 64) | (inc1 ? 0x80u : 0u) | tag;
+                    n_items += c0 + c1;
                 }
             }
         }
+        if (n_items) vote();
         wave_sync();
 #pragma unroll
         for (int k = 0; k < R; k++) {

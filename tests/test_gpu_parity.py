@@ -258,6 +258,46 @@ def test_start_grids_incremental_reward_vs_oracle(gs):
     _check_occ(env)
 
 
+@pytest.mark.parametrize('gs', [0, 16, 1])
+def test_single_colour_floors_vs_oracle(gs):
+    """Targets whose levels are full floors of one colour: one placed block matches up to 121 target cells at once
+    (the vote list of the histogram update overflows and is flushed), several envs of a wave change in the
+    same step, and translations / rotations are all admissible or all cut.  Oracle + fresh recount."""
+    from gridworld_amd import VecGridWorld
+    from oracle import oracle as O
+    n, T = 384, 260
+    tg = np.zeros((n, 9, 11, 11), np.int8)
+    st = np.zeros_like(tg)
+    rng = np.random.RandomState(12)
+    for e in range(n):
+        c = 1 + e % 3
+        tg[e, 0] = c                                 # a full floor
+        if e % 4 == 1:
+            tg[e, 1, 2:9, 2:9] = c                   # plus a smaller second storey of the same colour
+        if e % 4 == 2:
+            tg[e, 0, rng.randint(11), :] = 0         # a missing row: not every translation is admissible
+        if e % 5 == 3:
+            st[e, 0, 4:7, 4:7] = c                   # part of it already stands
+    kw = dict(size_reward=False, max_steps=1000)
+    env = VecGridWorld(n, autoreset=False, lanes_per_env=gs, **kw)
+    env.set_tasks(tg, st)
+    env.reset()
+    ob = O.OracleBatch(n, **kw)
+    ob.set_tasks(tg, st)
+    ob.reset()
+    # look down, then place / break a lot with the three colours in play (hotbar 1..3 = actions 6..8)
+    acts = rng.choice([1, 2, 3, 4, 6, 6, 7, 7, 8, 8, 12, 13, 14, 15, 16, 16, 17], size=(T, n)).astype(np.int32)
+    acts[:8] = 14
+    for t in range(T):
+        env.step(torch.as_tensor(acts[t]))
+        ob.step_walking(acts[t], nthreads=8)
+        if t % 20 == 19 or t == T - 1:
+            _compare(env, ob, f'step {t}')
+    assert env.stats()['changed'] > 20 * n // 10
+    _check_hist(env, tg, st, sample=range(0, n, 3))
+    _check_occ(env)
+
+
 def test_product_does_not_import_oracle():
     import sys
     import gridworld_amd  # noqa: F401
