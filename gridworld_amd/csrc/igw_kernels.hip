@@ -138,8 +138,12 @@ __device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_si
 __device__ inline uint32_t next_task(const KParams& p, int env, bool leader, int& task) {
     uint32_t ep = 0;
     if (p.episode) {
-        ep = __hip_atomic_load(p.episode + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (leader) p.episode[env] = ep + 1;
+        if (p.sample_tasks || p.rt_enabled || p.traj) {  // somebody needs the number: read, then count
+            ep = __hip_atomic_load(p.episode + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (leader) p.episode[env] = ep + 1;
+        } else if (leader) {  // just count: an atomic without return, nothing on the reset path waits for memory
+            __hip_atomic_fetch_add(p.episode + env, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (p.sample_tasks) {  // CustomTasks.reset on the device: uniform choice over the table
         task = rng_task(p.sample_seed, (uint64_t)(p.env_base + env), (uint64_t)ep, p.n_tasks);
@@ -625,18 +629,26 @@ __device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, i
     const char* hrow = reinterpret_cast<const char*>(p.hist + (size_t)env * HIST_ROW) + 16 * lane;
     if (L2) glds16_sc1(hrow, ws.hist[k]);  // cache policy sc1
     else glds16(hrow, ws.hist[k]);
-    // lanes 0-31: the 128 bytes from the dword holding the first byte of the target level (a level is 121
-    // bytes at an arbitrary offset of the 16-byte aligned, 1104-byte row: never leaves the row);
-    // lane 32: the dword with the starting grid's byte of the cell; lanes 33-36: the four bounding boxes
+    // aux row: dwords 0-31 = the 128 bytes from the dword holding the first byte of the target level (a level is
+    // 121 bytes at an arbitrary offset of the 16-byte aligned, 1104-byte row: never leaves the row); dword 32 = the
+    // dword with the starting grid's byte of the cell; dwords 33-36 = the four bounding boxes.  Three loads with
+    // wave-uniform bases (the LDS destination is M0 + 4 * lane either way).
     const int8_t* t4 = p.task_target + (size_t)task * STRIDE + (cell / LEVEL) * LEVEL;
     t4 -= reinterpret_cast<uintptr_t>(t4) & 3;
     const int8_t* s4 = p.task_start + (size_t)task * STRIDE + cell;
     s4 -= reinterpret_cast<uintptr_t>(s4) & 3;
     const int8_t* b4 = p.task_meta[task].bbox;
-    const int8_t* src = lane < 32 ? t4 + 4 * lane : lane == 32 ? s4 : b4 + 4 * (lane - 33);
-    if (lane < 37) {
-        if (L2) glds4_sc1(src, ws.aux[k]);  // the fused rollout may have regenerated this task row earlier in the launch
-        else glds4(src, ws.aux[k]);
+    if (lane < 32) {
+        if (L2) glds4_sc1(t4 + 4 * lane, ws.aux[k]);  // the fused rollout may have regenerated this task row earlier in the launch
+        else glds4(t4 + 4 * lane, ws.aux[k]);
+    }
+    if (lane == 32) {
+        if (L2) glds4_sc1(s4, ws.aux[k]);
+        else glds4(s4, ws.aux[k]);
+    }
+    if (lane >= 33 && lane < 37) {
+        if (L2) glds4_sc1(b4 + 4 * (lane - 33), ws.aux[k]);
+        else glds4(b4 + 4 * (lane - 33), ws.aux[k]);
     }
 }
 
@@ -704,7 +716,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         // and the fused rollout wait here
         if (L2 || base > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
-        int tv0[R], tv1[R], sv[R];
+        int tv0[R], tv1[R], sv[R], bbq[R];  // bbq: the bounding box of rotation (lane & 3), the one this lane votes for
         uint4 before[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
@@ -715,6 +727,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 tv0[k] = tb[lane];
                 tv1[k] = v1 ? tb[lane + 64] : 0;
                 sv[k] = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)r_task[k] * STRIDE + r_cell[k]) & 3];
+                bbq[k] = (int)ws.aux[k][33 + (lane & 3)];
             }
         }
         // Votes.  A target cell of the changed cell's level votes when its colour equals the cell's old synthetic
@@ -732,7 +745,9 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                     const int q = lane & 3, j = (int)(w & 0x7f), k = (int)((w >> 8) & 3);
                     const bool inc = (w & 0x80u) != 0;
                     const int gx = (int)((w >> 10) & 15), gz = (int)((w >> 14) & 15);
-                    const int bb = (int)ws.aux[k][33 + q];
+                    int bb = bbq[0];
+#pragma unroll
+                    for (int kk = 1; kk < R; kk++) bb = k == kk ? bbq[kk] : bb;
                     const int tx = j / 11, tz = j % 11;
                     // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
                     const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
