@@ -59,6 +59,8 @@ def load(build_if_missing=True):
         return _lib
     diag = os.environ.get('IGW_DIAG') == '1'
     path = os.path.join(HERE, 'libigw_hip_diag.so') if diag else LIB_PATH
+    if os.environ.get('IGW_LIB'):  # an explicitly built variant (tools/ab_variants.sh): A/B runs on one GPU box
+        path, build_if_missing = os.environ['IGW_LIB'], False
     if build_if_missing:
         from . import build as _build
         try:

@@ -312,6 +312,10 @@ __device__ inline int clampi(int v, int lo, int hi) { return min(max(v, lo), hi)
 __device__ inline int occ_idx(int x, int y, int z) {
     return (clampi(y, -4, 8) + 4) * OCC_LAYER + (clampi(x, -6, 6) + 6) * 13 + (clampi(z, -6, 6) + 6) + OCC_IDX0;
 }
+// occ_idx of the three clamped, offset coordinates packed in one word (xp | L << 8 | zp << 16): one v_dot4_u32_u8
+__device__ inline int key_idx(int key) {
+    return (int)__builtin_amdgcn_udot4((unsigned)key, 0x0001A90Du, (unsigned)OCC_IDX0, false);
+}
 __device__ inline bool occ_test(const uint32_t* occ_s, int idx) { return (occ_s[idx >> 5] >> (idx & 31)) & 1u; }
 
 // `key in world` (World.world dict membership, core/world.py:60-71 ground plane + placed blocks): one LDS
@@ -441,12 +445,22 @@ __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* o
     const double f1 = ax ? -1.0 : 1.0, f2 = ax ? 1.0 : -1.0;
     // the four probe cells differ from np only along this lane's axis (and one level down): the x and z terms
     // of the index take two values each, the level term four
+#ifdef IGW_AB_DOT4
+    // the four probe cells as packed keys (key_idx): x and z terms take two values each, the level four
+    const int ka = (clampi(nx + ux * i1, -6, 6) + 6) | ((clampi(nz + uz * i1, -6, 6) + 6) << 16);
+    const int kb = (clampi(nx - ux * i1, -6, 6) + 6) | ((clampi(nz - uz * i1, -6, 6) + 6) << 16);
+    const int la0 = (clampi(ny + uy * i1, -4, 8) + 4) << 8, la1 = (clampi(ny + uy * i1 - 1, -4, 8) + 4) << 8;
+    const int lb0 = (clampi(ny - uy * i1, -4, 8) + 4) << 8, lb1 = (clampi(ny - uy * i1 - 1, -4, 8) + 4) << 8;
+    const bool b1 = (int)occ_test(occ_s, key_idx(ka | la0)) | (int)occ_test(occ_s, key_idx(ka | la1));
+    const bool b2 = (int)occ_test(occ_s, key_idx(kb | lb0)) | (int)occ_test(occ_s, key_idx(kb | lb1));
+#else
     const int xa = (clampi(nx + ux * i1, -6, 6) + 6) * 13, xb = (clampi(nx - ux * i1, -6, 6) + 6) * 13;
     const int za = clampi(nz + uz * i1, -6, 6) + 6 + OCC_IDX0, zb = clampi(nz - uz * i1, -6, 6) + 6 + OCC_IDX0;
     const int ya0 = (clampi(ny + uy * i1, -4, 8) + 4) * OCC_LAYER, ya1 = (clampi(ny + uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
     const int yb0 = (clampi(ny - uy * i1, -4, 8) + 4) * OCC_LAYER, yb1 = (clampi(ny - uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
     const bool b1 = (int)occ_test(occ_s, ya0 + xa + za) | (int)occ_test(occ_s, ya1 + xa + za);
     const bool b2 = (int)occ_test(occ_s, yb0 + xb + zb) | (int)occ_test(occ_s, yb1 + xb + zb);
+#endif
     double d = (pa - na) * f1;
     const bool h1 = !(d < PAD) && b1;
     pa = h1 ? pa - (d - PAD) * f1 : pa;
@@ -476,9 +490,6 @@ struct Hit {
 // ground plane, whose first sample always differs from its predecessor in L; `previous` matters only inside
 // the zone, where nothing is clamped (the clamp range strictly contains the zone).
 constexpr double RINT_MAGIC = 0x1.8p52;
-__device__ inline int key_idx(int key) {  // occ_idx of a packed key: L*169 + xp*13 + zp + OCC_IDX0, one v_dot4_u32_u8
-    return (int)__builtin_amdgcn_udot4((unsigned)key, 0x0001A90Du, (unsigned)OCC_IDX0, false);
-}
 __device__ inline int key_of(double x, double y, double z) {
     const int xp = clampi(__double2loint(x + (RINT_MAGIC + 6.0)), 0, 12);
     const int l1 = clampi(__double2loint(y + (RINT_MAGIC + 4.0)), 0, 12);

@@ -412,6 +412,7 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
     constexpr bool FLY = MODE == MODE_FLY;
     const int m = e.tis;
     const double dt = m == 2 ? 0.05 / 2 : m == 4 ? 0.05 / 4 : m == 8 ? 0.05 / 8 : 0.05 / 12;
+    [[maybe_unused]] double vy_pre = 0.0;
     for (int i = 0; i < (IGW_DIAG_FLAG(p, 4) ? 0 : m); i++) {  // _update, :222-262
         const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
         const double d = dt * speed;
@@ -419,10 +420,14 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
         double ddy = mv.y * d;
         if (!FLY) {
             e.vy -= dt * GRAVITY;
+#ifdef IGW_AB_TIS
+            vy_pre = e.vy;  // time_int_steps follows the velocity of the LAST sub-step (it is overwritten by every one)
+#else
             if (e.vy < -14.0) e.tis = 12;
             else if (e.vy < -10.0) e.tis = 8;
             else if (e.vy < -5.0) e.tis = 4;
             else e.tis = 2;
+#endif
             e.vy = e.vy > -TERMINAL_VELOCITY ? e.vy : -TERMINAL_VELOCITY;
         }
         ddy += e.vy * dt;
@@ -435,6 +440,9 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
             e.x = cx; e.y = cy; e.z = cz;
         }
     }
+#ifdef IGW_AB_TIS
+    if (!FLY && !IGW_DIAG_FLAG(p, 4)) e.tis = vy_pre < -14.0 ? 12 : vy_pre < -10.0 ? 8 : vy_pre < -5.0 ? 4 : 2;
+#endif
     if (FLY) e.vy = 0.0;
     // yaw wrap with strict comparisons (0 and 360 both survive), :451-456
     while (e.yaw > 360.0) e.yaw -= 360.0;
@@ -631,24 +639,17 @@ __device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, i
     else glds16(hrow, ws.hist[k]);
     // aux row: dwords 0-31 = the 128 bytes from the dword holding the first byte of the target level (a level is
     // 121 bytes at an arbitrary offset of the 16-byte aligned, 1104-byte row: never leaves the row); dword 32 = the
-    // dword with the starting grid's byte of the cell; dwords 33-36 = the four bounding boxes.  Three loads with
-    // wave-uniform bases (the LDS destination is M0 + 4 * lane either way).
+    // dword with the starting grid's byte of the cell; dwords 33-36 = the four bounding boxes.
     const int8_t* t4 = p.task_target + (size_t)task * STRIDE + (cell / LEVEL) * LEVEL;
     t4 -= reinterpret_cast<uintptr_t>(t4) & 3;
     const int8_t* s4 = p.task_start + (size_t)task * STRIDE + cell;
     s4 -= reinterpret_cast<uintptr_t>(s4) & 3;
     const int8_t* b4 = p.task_meta[task].bbox;
-    if (lane < 32) {
-        if (L2) glds4_sc1(t4 + 4 * lane, ws.aux[k]);  // the fused rollout may have regenerated this task row earlier in the launch
-        else glds4(t4 + 4 * lane, ws.aux[k]);
-    }
-    if (lane == 32) {
-        if (L2) glds4_sc1(s4, ws.aux[k]);
-        else glds4(s4, ws.aux[k]);
-    }
-    if (lane >= 33 && lane < 37) {
-        if (L2) glds4_sc1(b4 + 4 * (lane - 33), ws.aux[k]);
-        else glds4(b4 + 4 * (lane - 33), ws.aux[k]);
+    // one load instruction, per-lane source (measured faster than three loads with wave-uniform bases)
+    const int8_t* src = lane < 32 ? t4 + 4 * lane : lane == 32 ? s4 : b4 + 4 * (lane - 33);
+    if (lane < 37) {
+        if (L2) glds4_sc1(src, ws.aux[k]);  // the fused rollout may have regenerated this task row earlier in the launch
+        else glds4(src, ws.aux[k]);
     }
 }
 
@@ -716,18 +717,19 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         // and the fused rollout wait here
         if (L2 || base > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
-        int tv0[R], tv1[R], sv[R], bbq[R];  // bbq: the bounding box of rotation (lane & 3), the one this lane votes for
+        int tv0[R], tv1[R], sv[R];
         uint4 before[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
+#ifndef IGW_AB_FULLROW
                 before[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+#endif
                 const int8_t* trow = p.task_target + (size_t)r_task[k] * STRIDE + (r_cell[k] / LEVEL) * LEVEL;
                 const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) + (reinterpret_cast<uintptr_t>(trow) & 3);
                 tv0[k] = tb[lane];
                 tv1[k] = v1 ? tb[lane + 64] : 0;
                 sv[k] = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)r_task[k] * STRIDE + r_cell[k]) & 3];
-                bbq[k] = (int)ws.aux[k][33 + (lane & 3)];
             }
         }
         // Votes.  A target cell of the changed cell's level votes when its colour equals the cell's old synthetic
@@ -745,9 +747,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                     const int q = lane & 3, j = (int)(w & 0x7f), k = (int)((w >> 8) & 3);
                     const bool inc = (w & 0x80u) != 0;
                     const int gx = (int)((w >> 10) & 15), gz = (int)((w >> 14) & 15);
-                    int bb = bbq[0];
-#pragma unroll
-                    for (int kk = 1; kk < R; kk++) bb = k == kk ? bbq[kk] : bb;
+                    const int bb = (int)ws.aux[k][33 + q];  // (measured faster than keeping the boxes in registers)
                     const int tx = j / 11, tz = j % 11;
                     // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
                     const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
@@ -792,8 +792,12 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
                 const uint4 now = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
+#ifdef IGW_AB_FULLROW
+                reinterpret_cast<uint4*>(p.hist + (size_t)r_env[k] * HIST_ROW)[lane] = now;
+#else
                 if (now.x != before[k].x || now.y != before[k].y || now.z != before[k].z || now.w != before[k].w)
                     reinterpret_cast<uint4*>(p.hist + (size_t)r_env[k] * HIST_ROW)[lane] = now;
+#endif
                 const uint32_t m01 = max(max(now.x & 0xffff, now.x >> 16), max(now.y & 0xffff, now.y >> 16));
                 const uint32_t m23 = max(max(now.z & 0xffff, now.z >> 16), max(now.w & 0xffff, now.w >> 16));
                 const int best = wave_max_nonneg((int)max(m01, m23));
