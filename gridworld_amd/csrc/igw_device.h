@@ -22,7 +22,10 @@
 namespace igw {
 
 constexpr int WAVE = 64;
-constexpr int BLOCK = 256;
+#ifndef IGW_BLOCK
+#define IGW_BLOCK 256
+#endif
+constexpr int BLOCK = IGW_BLOCK;
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
 constexpr int CELLS = IGW_CELLS;
 constexpr int STRIDE = IGW_GRID_STRIDE;
@@ -445,22 +448,12 @@ __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* o
     const double f1 = ax ? -1.0 : 1.0, f2 = ax ? 1.0 : -1.0;
     // the four probe cells differ from np only along this lane's axis (and one level down): the x and z terms
     // of the index take two values each, the level term four
-#ifdef IGW_AB_DOT4
-    // the four probe cells as packed keys (key_idx): x and z terms take two values each, the level four
-    const int ka = (clampi(nx + ux * i1, -6, 6) + 6) | ((clampi(nz + uz * i1, -6, 6) + 6) << 16);
-    const int kb = (clampi(nx - ux * i1, -6, 6) + 6) | ((clampi(nz - uz * i1, -6, 6) + 6) << 16);
-    const int la0 = (clampi(ny + uy * i1, -4, 8) + 4) << 8, la1 = (clampi(ny + uy * i1 - 1, -4, 8) + 4) << 8;
-    const int lb0 = (clampi(ny - uy * i1, -4, 8) + 4) << 8, lb1 = (clampi(ny - uy * i1 - 1, -4, 8) + 4) << 8;
-    const bool b1 = (int)occ_test(occ_s, key_idx(ka | la0)) | (int)occ_test(occ_s, key_idx(ka | la1));
-    const bool b2 = (int)occ_test(occ_s, key_idx(kb | lb0)) | (int)occ_test(occ_s, key_idx(kb | lb1));
-#else
     const int xa = (clampi(nx + ux * i1, -6, 6) + 6) * 13, xb = (clampi(nx - ux * i1, -6, 6) + 6) * 13;
     const int za = clampi(nz + uz * i1, -6, 6) + 6 + OCC_IDX0, zb = clampi(nz - uz * i1, -6, 6) + 6 + OCC_IDX0;
     const int ya0 = (clampi(ny + uy * i1, -4, 8) + 4) * OCC_LAYER, ya1 = (clampi(ny + uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
     const int yb0 = (clampi(ny - uy * i1, -4, 8) + 4) * OCC_LAYER, yb1 = (clampi(ny - uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
     const bool b1 = (int)occ_test(occ_s, ya0 + xa + za) | (int)occ_test(occ_s, ya1 + xa + za);
     const bool b2 = (int)occ_test(occ_s, yb0 + xb + zb) | (int)occ_test(occ_s, yb1 + xb + zb);
-#endif
     double d = (pa - na) * f1;
     const bool h1 = !(d < PAD) && b1;
     pa = h1 ? pa - (d - PAD) * f1 : pa;

@@ -420,14 +420,7 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
         double ddy = mv.y * d;
         if (!FLY) {
             e.vy -= dt * GRAVITY;
-#ifdef IGW_AB_TIS
-            vy_pre = e.vy;  // time_int_steps follows the velocity of the LAST sub-step (it is overwritten by every one)
-#else
-            if (e.vy < -14.0) e.tis = 12;
-            else if (e.vy < -10.0) e.tis = 8;
-            else if (e.vy < -5.0) e.tis = 4;
-            else e.tis = 2;
-#endif
+            vy_pre = e.vy;  // time_int_steps (:243-250) is overwritten by every sub-step: only the last one's counts
             e.vy = e.vy > -TERMINAL_VELOCITY ? e.vy : -TERMINAL_VELOCITY;
         }
         ddy += e.vy * dt;
@@ -440,9 +433,7 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
             e.x = cx; e.y = cy; e.z = cz;
         }
     }
-#ifdef IGW_AB_TIS
     if (!FLY && !IGW_DIAG_FLAG(p, 4)) e.tis = vy_pre < -14.0 ? 12 : vy_pre < -10.0 ? 8 : vy_pre < -5.0 ? 4 : 2;
-#endif
     if (FLY) e.vy = 0.0;
     // yaw wrap with strict comparisons (0 and 360 both survive), :451-456
     while (e.yaw > 360.0) e.yaw -= 360.0;
@@ -722,9 +713,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
 #pragma unroll
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
-#ifndef IGW_AB_FULLROW
                 before[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
-#endif
                 const int8_t* trow = p.task_target + (size_t)r_task[k] * STRIDE + (r_cell[k] / LEVEL) * LEVEL;
                 const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) + (reinterpret_cast<uintptr_t>(trow) & 3);
                 tv0[k] = tb[lane];
@@ -792,12 +781,8 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         for (int k = 0; k < R; k++) {
             if (k < cnt) {
                 const uint4 now = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
-#ifdef IGW_AB_FULLROW
-                reinterpret_cast<uint4*>(p.hist + (size_t)r_env[k] * HIST_ROW)[lane] = now;
-#else
                 if (now.x != before[k].x || now.y != before[k].y || now.z != before[k].z || now.w != before[k].w)
                     reinterpret_cast<uint4*>(p.hist + (size_t)r_env[k] * HIST_ROW)[lane] = now;
-#endif
                 const uint32_t m01 = max(max(now.x & 0xffff, now.x >> 16), max(now.y & 0xffff, now.y >> 16));
                 const uint32_t m23 = max(max(now.z & 0xffff, now.z >> 16), max(now.w & 0xffff, now.w >> 16));
                 const int best = wave_max_nonneg((int)max(m01, m23));
@@ -964,6 +949,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     // the histogram row, target level, start byte and bounding boxes of every changed env start moving into
     // LDS now and land while the physics runs
     const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env_r, task, ch);
+#ifdef IGW_AB_PRIO
+    if (chg_mask) __builtin_amdgcn_s_setprio(IGW_AB_PRIO);  // waves with a histogram update ahead of them go first
+#endif
     if (MODE == MODE_FLY) world_update<GS, MODE_FLY>(G, p, e, occ_s, mv);
     else world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
     finish_break(e, ch);
