@@ -168,9 +168,9 @@ def load_profile(suffix):
 def auto_lanes(n):
     """The library's automatic group width (include/igw.h: IGW_TARGET_WAVES)."""
     lanes = 64
-    while lanes > 1 and n * lanes // 64 > 4096:
+    while lanes > 4 and n * lanes // 64 > 1024:
         lanes //= 2
-    return 4 if lanes == 2 else lanes
+    return lanes
 
 
 def dry_run(args):

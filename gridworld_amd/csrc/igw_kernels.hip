@@ -949,9 +949,6 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     // the histogram row, target level, start byte and bounding boxes of every changed env start moving into
     // LDS now and land while the physics runs
     const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env_r, task, ch);
-#ifdef IGW_AB_PRIO
-    if (chg_mask) __builtin_amdgcn_s_setprio(IGW_AB_PRIO);  // waves with a histogram update ahead of them go first
-#endif
     if (MODE == MODE_FLY) world_update<GS, MODE_FLY>(G, p, e, occ_s, mv);
     else world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
     finish_break(e, ch);
@@ -1401,12 +1398,12 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
         return fail(IGW_ERR_INVALID, "igw_create: unknown action_space");
     int gs = cfg->lanes_per_env;
     if (gs == 0) {
-        // auto: aim at ~IGW_TARGET_WAVES wavefronts per launch (4 per SIMD on MI355X) -- fewer leave the
-        // SIMDs without latency hiding, more only add redundant per-lane physics.  Measured optima:
-        // 4,096 envs -> 16..64 lanes, 16,384 -> 16, 65,536 -> 4, 262,144 -> 1.
+        // auto: four lanes per env (coordinate-split ray march, axis-split collide) measured fastest at every batch
+        // from 16,384 envs up to 1,048,576 (2.2.. 5.6 G env-steps/s); smaller batches take wider groups so that a
+        // launch still has about IGW_TARGET_WAVES wavefronts (one per SIMD) to spread over the chip:
+        // 4,096 envs -> 16 lanes, 1,024 -> 64.
         gs = 64;
-        while (gs > 1 && (long long)cfg->num_envs * gs / 64 > IGW_TARGET_WAVES) gs >>= 1;
-        if (gs == 2) gs = 4;  // 4 lanes unlock the lane-split collide / trig; measured faster than 2 at every N
+        while (gs > 4 && (long long)cfg->num_envs * gs / 64 > IGW_TARGET_WAVES) gs >>= 1;
     }
 #ifndef IGW_DIAG
     if (cfg->reserved != 0)

@@ -35,10 +35,11 @@ extern "C" {
 #endif
 
 #define IGW_VERSION 2
-/* igw_config.lanes_per_env == 0 picks the widest power-of-two lane group (64 = one wavefront per env ... 1 =
- * one lane per env) that keeps a launch at or below this many wavefronts (4 per SIMD on MI355X), except
- * that 2 is never chosen (4 lanes unlock the lane-split collide and trig).  65,536 envs -> 4 lanes per env. */
-#define IGW_TARGET_WAVES 4096
+/* igw_config.lanes_per_env == 0 picks the group width: 4 lanes per env from 16,384 envs up (measured fastest at
+ * every larger batch), wider power-of-two groups (8, 16, ... 64 = one wavefront per env) for smaller batches so
+ * that a launch keeps about this many wavefronts (one per SIMD of an MI355X).  1 and 2 lanes per env exist and
+ * are tested, but are never chosen automatically. */
+#define IGW_TARGET_WAVES 1024
 
 /* dense voxel grid [y+1][x+5][z+5], int8 (env.py:34, 136-142) */
 #define IGW_GRID_Y 9
@@ -97,7 +98,7 @@ typedef struct igw_config {
     int32_t autoreset;         /* 0: caller resets on done (reference loop); 1: reset inside step */
     double right_placement_scale; /* env.py:335 */
     double wrong_placement_scale; /* env.py:337 */
-    int32_t lanes_per_env;     /* 0 = automatic from num_envs (see IGW_TARGET_WAVES); or 64,32,...,1 */
+    int32_t lanes_per_env;     /* 0 = automatic from num_envs (see IGW_TARGET_WAVES); or 64, 32, ..., 1 */
     int32_t reserved;          /* must be 0 (ablation switches of the IGW_DIAG build) */
     int64_t env_index_base;    /* global index of env 0 of this context (rank offset, sub-batch offset): keys the
                                 * on-device task samplers so shards and sub-batches draw different streams */

@@ -1,1 +1,14 @@
-for g in 64 32 16 8 4 2 1; do python bench.py --lanes-per-env $g --no-cpu-baseline --steps 250 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('GS',d['config']['lanes_per_env'], '%.1fM steps/s' % (d['value']/1e6), 'kernel_ms %.4f' % d['roofline']['kernel_avg_ms'], 'ms/step %.4f' % d['ms_per_step'], 'fused %.1fM' % (d['config']['fused_rollout_env_steps_per_s']/1e6))"; done
+#!/bin/bash
+# Diagnostic (GPU box): env-steps/s over batch size x lanes per env, to (re)tune the automatic group width.
+set -u
+export TMPDIR=/tmp
+for N in 4096 16384 65536 131072 262144 1048576; do
+  for GS in 64 16 8 4 2 1; do
+    W=$((N * GS / 64))
+    if [ $W -lt 512 ] || [ $W -gt 70000 ]; then continue; fi
+    K=$((20000000 / N)); [ $K -gt 400 ] && K=400; [ $K -lt 30 ] && K=30
+    python3 bench.py --no-cpu-baseline --no-fused --steps $K --warmup 10 --envs-per-gpu $N --lanes-per-env $GS 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N $N lanes $GS waves $W: %.3f G  kernel %.2f us' % (d['value']/1e9, d['roofline']['kernel_avg_ms']*1e3))"
+  done
+done
