@@ -7,4 +7,4 @@ for F in 0 16 32 48 1 2 4 7 55; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('flags $F kernel %.2f us' % (d['roofline']['kernel_avg_ms']*1e3))"
 done
-python3 tools/stamp_phases.py gpurun_out/s6/st16.npz 4 24 | sed -n 2,10p
+

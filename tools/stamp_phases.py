@@ -63,6 +63,19 @@ for label, m in (('no change, no reset', (n_ch == 0) & (n_rt == 0)), ('1 change'
     if m.any():
         print(f'    {label:20s} share {m.mean():6.3f}  lifetime mean {life[m].mean():8.0f}  p99 {np.percentile(life[m], 99):8.0f}'
               f'  hist phase {d[:, :, 4][m].mean():7.0f}  last phase {d[:, :, 5][m].mean():7.0f}')
+# by dispatch order: blocks are dealt to the CUs in index order, so block // 256 is the age rank of a wave on its SIMD
+grp = (np.arange(waves) // 4) // max(1, (waves // 4) // 4)
+print('  by block dispatch order (= wave age on its SIMD; issue is arbitrated by age):')
+for g_ in range(4):
+    m = grp == g_
+    print(f'    blocks {g_ * (waves // 16):5d}+  lifetime mean {life[:, m].mean():7.0f}  max {life[:, m].max(1).mean():7.0f}  ' +
+          '  '.join(f'{nm.split()[0]} {d[:, m, i].mean():6.0f}' for i, nm in enumerate(names)))
+young = grp == 3
+print('  youngest quarter, no reset, by changed envs in the wave:')
+for k in range(8):
+    m = young[None, :] & (n_ch == k) & (n_rt == 0)
+    if m.sum() > 5:
+        print(f'    {k} changes: n {int(m.sum()):6d}  lifetime {life[m].mean():7.0f}  histogram phase {d[:, :, 4][m].mean():6.0f}  physics {d[:, :, 2][m].mean():6.0f}')
 # which waves end last
 last = life.argmax(1)
 print('  slowest wave per launch: changes', n_ch[np.arange(len(last)), last].tolist())
