@@ -268,13 +268,23 @@ def main():
             for t in range(W + head, W + K):
                 step(t)
         torch.cuda.current_stream(device).wait_stream(cap)
-        torch.cuda.synchronize(device)
+        # part of the setup, like the pre-roll: the first launch of a graph also uploads it, and a GPU that has
+        # been idle (fresh process, task upload from the host) needs some tens of milliseconds of work to reach
+        # its working clocks -- without this a 20-step window measures the clock ramp, not the kernel
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < 0.3:
+            for _ in range(8):
+                graph.replay()
+            torch.cuda.synchronize(device)
     # W untimed warm-up steps right before the clock (the chip is at its working clocks when timing starts); the
     # counters are snapshotted on the device, not read, so nothing idles the GPU between warm-up and clock
     for t in range(W):
         step(t)
     st0_dev = env.stats_buf.sum(0)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()   # torch creates the HIP events lazily at their first record(): not inside the clock
+    ev1.record()
+    ev1.query()
     gdist.barrier(device)
     torch.cuda.synchronize(device)
     t_start = time.perf_counter()
@@ -344,6 +354,7 @@ def main():
                    'launches_per_step': 1,
                    'timed_as': 'eager launches' if graph is None else f'{head} eager launches + one HIP-graph replay of the other {K - head}',
                    'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + 250-step pre-roll)',
+                   'setup': 'untimed: task upload, pre-roll, graph capture + 0.3 s of graph replays (clock ramp), then the W warm-up steps',
                    'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
