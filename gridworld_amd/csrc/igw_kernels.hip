@@ -523,9 +523,6 @@ struct BlockShared {
     static constexpr int EPW = WAVE / GS;   // envs per wave
     alignas(16) uint32_t occ[EPB * OCC_PITCH];  // occupancy rows, one per env
     WaveScratch<req_chunk<GS>()> ws[WAVES_PER_BLOCK];
-#ifdef IGW_LDS_PAD
-    char pad[IGW_LDS_PAD];  // experiment: fewer resident blocks per CU, i.e. several rounds of younger blocks
-#endif
 };
 
 __constant__ double IGW_TRIG_LUT_DEV[IGW_LUT_N * 2];
