@@ -359,7 +359,7 @@ def main():
                    'fused_rollout_env_steps_per_s': fused},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': hbm_bytes,
-                     'kernel': 'igw::step_kernel<%d, %d>' % (lanes, 1 if flying else 0), 'kernel_avg_ms': kernel_ms,
+                     'kernel': 'igw::step_kernel<%d, %d, false>' % (lanes, 1 if flying else 0), 'kernel_avg_ms': kernel_ms,
                      'algorithmic_bytes_per_env_step': bytes_per_step,
                      'algorithmic_bytes_per_launch': N * bytes_per_step,
                      # what the memory system really moved (committed PMC profile) over this run's kernel time:

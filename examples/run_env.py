@@ -3,6 +3,8 @@
 
     python examples/run_env.py                 # 1-env gym-shaped facade (API parity; latency-bound)
     python examples/run_env.py --vec 65536     # N envs, tensor observations (the fast path)
+    python examples/run_env.py --vec 65536 --random-tasks      # RandomTasks.sample_task on the device at every reset
+    python examples/run_env.py --vec 4096 --log 2 episodes/    # dump the episodes of the first 2 envs (Logged-style npz)
 """
 import argparse
 import os
@@ -33,9 +35,16 @@ def single(episodes):
     print(f'steps per second: {steps / time:.4f}')
 
 
-def vec(n, steps):
+def vec(n, steps, random_tasks=False, log=None):
     env = G.make_vec(n, size_reward=False, autoreset=True)
-    env.set_tasks(G.workloads.rt20(n, seed=0, device=env.device))
+    if random_tasks:   # RandomTasks(max_blocks=20, max_dist=2, num_colors=6), sampled on the device at every reset
+        env.set_random_tasks(True, seed=0, max_blocks=20, height_levels=1, max_dist=2, num_colors=6)
+    else:
+        env.set_tasks(G.workloads.rt20(n, seed=0, device=env.device))
+    logger = None
+    if log:
+        from gridworld_amd.wrappers import EpisodeLogger
+        logger = EpisodeLogger(env, n_envs=int(log[0]), path=log[1], desc='example')
     env.reset()
     actions = torch.randint(0, 18, (steps, n), dtype=torch.int32, device=env.device)
     torch.cuda.synchronize()
@@ -44,7 +53,10 @@ def vec(n, steps):
         obs, reward, done, info = env.step(actions[k])   # tensors in HBM; a policy would read obs here
     torch.cuda.synchronize()
     dt = perf_counter() - t
-    print(f'{n} envs x {steps} steps: {n * steps / dt / 1e6:.1f} M env-steps per second')
+    print(f'{n} envs x {steps} steps: {n * steps / dt / 1e6:.1f} M env-steps per second; counters {env.stats()}')
+    if logger:
+        files = [ep['file'] for ep in logger.collect()]
+        print(f'{len(files)} finished episodes of the logged envs written, e.g. {files[:2]}')
 
 
 if __name__ == '__main__':
@@ -52,5 +64,7 @@ if __name__ == '__main__':
     ap.add_argument('--vec', type=int, default=0)
     ap.add_argument('--episodes', type=int, default=4)
     ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--random-tasks', action='store_true')
+    ap.add_argument('--log', nargs=2, metavar=('N_ENVS', 'DIR'))
     a = ap.parse_args()
-    vec(a.vec, a.steps) if a.vec else single(a.episodes)
+    vec(a.vec, a.steps, a.random_tasks, a.log) if a.vec else single(a.episodes)
