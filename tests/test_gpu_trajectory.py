@@ -146,3 +146,32 @@ def test_input_validation_and_counters():
         L.check(w.lib.igw_create(C.byref(cfg), C.byref(ctx)), 'igw_create')     # ablation switches: IGW_DIAG build only
     with pytest.raises(IgwError):
         L.check(w.lib.igw_debug_set_stamps(w.ctx, None), 'stamps')
+
+
+def test_logged_wrapper_on_the_facade(tmp_path):
+    """The reference's calling sequence: Logged(env); turn_on(); set_path(); an npz per finished episode
+    (wrappers.py:66-134), here checked against a fixture replayed through the 1-env facade."""
+    import gridworld_amd as G
+    from gridworld_amd.wrappers import Logged
+    fx = GR.load_fixture('s5_scripted_leak')      # max_steps = 12: several short episodes
+    e = 1
+    env = Logged(G.make('IGLUGridworldVector-v0', **fx['kwargs']))
+    env.set_path(str(tmp_path))
+    env.set_desc('facade', 3)
+    env.set_task(G.Task('', fx['targets'][e].astype(np.int32), starting_grid=G.Tasks.to_sparse(fx['starts'][e].astype(np.int32))))
+    env.reset()
+    assert env.max_steps == fx['kwargs']['max_steps']          # attribute pass-through to the wrapped env
+    n_done = 0
+    for t in range(fx['done'].shape[1]):
+        if fx['reset_before'][e, t]:
+            env.reset()
+        if t == 13:
+            env.turn_on()                                        # episodes that end from here on are written
+        obs, reward, done, _ = env.step(int(fx['actions'][e, t]))
+        assert done == bool(fx['done'][e, t])
+        n_done += done
+    files = sorted(p for p in (tmp_path / 'step3').iterdir() if p.suffix == '.npz')
+    assert n_done >= 3 and len(files) == n_done - 1              # the first episode ended before turn_on()
+    z = np.load(files[0])
+    assert z['agentPos'].shape[1:] == (5,) and z['grid'].shape[1:] == (9, 11, 11) and len(z['reward']) == len(z['done'])
+    assert z['done'][-1] and len(z['agentPos']) == len(z['reward']) + 1
