@@ -14,7 +14,7 @@ maximal_intersection reward), uniform random actions that are already resident i
 region starts.  Weak scaling: every rank owns its own 65,536 envs; no data-path collective.
 
 Steady state before the clock: episodes are de-synchronised (every env starts at a random step of its
-episode, then one untimed 250-step pre-roll), so any timed window -- also a 20-step one -- sees the
+episode, then an untimed pre-roll of at least 250 steps and 0.3 s), so any timed window -- also a 20-step one -- sees the
 steady-state fraction of grid-changing steps and about N/250 auto-resets per launch.  The K timed
 launches are 2 eager launches followed by ONE HIP-graph replay of the other K - 2 (captured and
 instantiated before the clock), inside the barrier / synchronize bracket, so a short window is
@@ -234,11 +234,15 @@ def main():
             L.check(env.lib.igw_step_flying(env.ctx, a[0][t].data_ptr(), a[1][t].data_ptr(), a[2][t].data_ptr(),
                                             a[3][t].data_ptr(), env._stream()), 'igw_step_flying')
         if not args.lockstep:
-            for _ in range(MAX_STEPS // 50):  # untimed pre-roll to the steady state
+            # untimed pre-roll to the steady state: at least one episode length, and at least 0.3 s of work so a GPU
+            # that has been idle (fresh process, task upload) is at its working clocks -- always FRESH random actions
+            t_ramp, n_pre = time.perf_counter(), 0
+            while n_pre < MAX_STEPS or time.perf_counter() - t_ramp < 0.3:
                 pre = fly_actions(50)
                 for t in range(50):
                     fly_step(pre, t)
-            torch.cuda.synchronize(device)
+                torch.cuda.synchronize(device)
+                n_pre += 50
             del pre
         acts = fly_actions(W + K)
 
@@ -246,7 +250,14 @@ def main():
             fly_step(acts, t)
     else:
         if not args.lockstep:
-            env.rollout(MAX_STEPS, seed=args.seed + 17, t0=0, env_offset=env_offset)  # untimed pre-roll
+            # untimed pre-roll to the steady state (fused rollout, in-kernel random actions): at least one episode
+            # length, and at least 0.3 s of work so a GPU that has been idle (fresh process, task upload) is at its
+            # working clocks -- without it a 20-step window measures the clock ramp, not the kernel
+            t_ramp, n_pre = time.perf_counter(), 0
+            while n_pre < MAX_STEPS or time.perf_counter() - t_ramp < 0.3:
+                env.rollout(MAX_STEPS, seed=args.seed + 17 + n_pre, t0=n_pre, env_offset=env_offset)
+                torch.cuda.synchronize(device)
+                n_pre += MAX_STEPS
         chunk = 256
         actions = [env.fill_actions(min(chunk, W + K - t0), seed=args.seed, t0=t0, env_offset=env_offset)
                    for t0 in range(0, W + K, chunk)]
@@ -268,14 +279,8 @@ def main():
             for t in range(W + head, W + K):
                 step(t)
         torch.cuda.current_stream(device).wait_stream(cap)
-        # part of the setup, like the pre-roll: the first launch of a graph also uploads it, and a GPU that has
-        # been idle (fresh process, task upload from the host) needs some tens of milliseconds of work to reach
-        # its working clocks -- without this a 20-step window measures the clock ramp, not the kernel
-        t_ramp = time.perf_counter()
-        while time.perf_counter() - t_ramp < 0.3:
-            for _ in range(8):
-                graph.replay()
-            torch.cuda.synchronize(device)
+        graph.replay()  # part of the setup: the first launch of a graph also uploads it
+        torch.cuda.synchronize(device)
     # W untimed warm-up steps right before the clock (the chip is at its working clocks when timing starts); the
     # counters are snapshotted on the device, not read, so nothing idles the GPU between warm-up and clock
     for t in range(W):
@@ -353,8 +358,8 @@ def main():
                    'envs_per_gpu': N, 'total_envs': N * n_ranks, 'lanes_per_env': lanes,
                    'launches_per_step': 1,
                    'timed_as': 'eager launches' if graph is None else f'{head} eager launches + one HIP-graph replay of the other {K - head}',
-                   'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + 250-step pre-roll)',
-                   'setup': 'untimed: task upload, pre-roll, graph capture + 0.3 s of graph replays (clock ramp), then the W warm-up steps',
+                   'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + pre-roll)',
+                   'setup': 'untimed: task upload, pre-roll of >= 250 steps and >= 0.3 s with fresh random actions (steady state, clock ramp), graph capture + one replay, then the W warm-up steps',
                    'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
