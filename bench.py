@@ -31,6 +31,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
                   a bounded sample of the same workload (N = 1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -245,9 +246,16 @@ def main():
                 n_pre += 50
             del pre
         acts = fly_actions(W + K)
+        # the timed loop passes pre-computed device pointers: slicing a tensor per step costs more host time
+        # than the launch itself
+        fptrs = [tuple(a[t].data_ptr() for a in acts) for t in range(W + K)]
+        fly_fn, ctx_h = env.lib.igw_step_flying, env.ctx
 
-        def step(t):
-            fly_step(acts, t)
+        def step(t, stream):
+            p = fptrs[t]
+            rc = fly_fn(ctx_h, p[0], p[1], p[2], p[3], stream)
+            if rc:
+                L.check(rc, 'igw_step_flying')
     else:
         if not args.lockstep:
             # untimed pre-roll to the steady state (fused rollout, in-kernel random actions): at least one episode
@@ -262,8 +270,17 @@ def main():
         actions = [env.fill_actions(min(chunk, W + K - t0), seed=args.seed, t0=t0, env_offset=env_offset)
                    for t0 in range(0, W + K, chunk)]
 
-        def step(t):
-            env.step_walking_ptr(actions[t // chunk][t % chunk])
+        # the timed loop passes pre-computed device pointers: slicing a tensor per step costs more host time
+        # than the launch itself (tools/window_variants.py: 3.5 us per launch this way, 9-17 us through the
+        # tensor-slicing wrapper)
+        wptrs = [actions[t // chunk][t % chunk].data_ptr() for t in range(W + K)]
+        walk_fn, ctx_h = env.lib.igw_step_walking, env.ctx
+        from gridworld_amd import _lib as L
+
+        def step(t, stream):
+            rc = walk_fn(ctx_h, wptrs[t], stream)
+            if rc:
+                L.check(rc, 'igw_step_walking')
 
     # The timed launches as a short eager head + ONE HIP graph for the rest.  Capture records launches without
     # running them (the entry points never synchronise or allocate) and instantiation happens here, before the
@@ -276,15 +293,17 @@ def main():
         cap = torch.cuda.Stream(device=device)
         cap.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.graph(graph, stream=cap):
+            cap_h = ctypes.c_void_p(cap.cuda_stream)
             for t in range(W + head, W + K):
-                step(t)
+                step(t, cap_h)
         torch.cuda.current_stream(device).wait_stream(cap)
         graph.replay()  # part of the setup: the first launch of a graph also uploads it
         torch.cuda.synchronize(device)
     # W untimed warm-up steps right before the clock (the chip is at its working clocks when timing starts); the
     # counters are snapshotted on the device, not read, so nothing idles the GPU between warm-up and clock
+    cur_h = env._stream()
     for t in range(W):
-        step(t)
+        step(t, cur_h)
     st0_dev = env.stats_buf.sum(0)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()   # torch creates the HIP events lazily at their first record(): not inside the clock
@@ -292,18 +311,29 @@ def main():
     ev1.query()
     gdist.barrier(device)
     torch.cuda.synchronize(device)
+    ev0.record()   # the event window opens just before the wall clock and closes inside it
     t_start = time.perf_counter()
-    ev0.record()
+    t_a = time.perf_counter()
     for t in range(W, W + head):
-        step(t)
+        step(t, cur_h)
+    t_b = time.perf_counter()
     if graph is not None:
         graph.replay()
+    t_c = time.perf_counter()
     ev1.record()
+    t_d = time.perf_counter()
     while not ev1.query():  # spin: a blocking synchronize sleeps on an interrupt and wakes tens of microseconds late
         pass
+    t_e = time.perf_counter()
     torch.cuda.synchronize(device)
+    t_f = time.perf_counter()
     gdist.barrier(device)
     elapsed = time.perf_counter() - t_start
+    if os.environ.get('IGW_BENCH_TRACE'):
+        print('host us: - %.1f | head launches %.1f | graph launch %.1f | ev1.record %.1f | spin %.1f | '
+              'synchronize %.1f | barrier %.1f | total %.1f' % tuple(1e6 * x for x in (
+                  t_a - t_start, t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e,
+                  elapsed - (t_f - t_start), elapsed)), file=sys.stderr)
     from gridworld_amd import _lib as _L
     s0 = st0_dev.cpu()
     st0 = {'changed': int(s0[_L.STAT_CHANGED]), 'resets': int(s0[_L.STAT_RESETS])}
