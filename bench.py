@@ -14,11 +14,13 @@ maximal_intersection reward), uniform random actions that are already resident i
 region starts.  Weak scaling: every rank owns its own 65,536 envs; no data-path collective.
 
 Steady state before the clock: episodes are de-synchronised (every env starts at a random step of its
-episode, then an untimed pre-roll of at least 250 steps and 0.3 s), so any timed window -- also a 20-step one -- sees the
-steady-state fraction of grid-changing steps and about N/250 auto-resets per launch.  The K timed
-launches are 2 eager launches followed by ONE HIP-graph replay of the other K - 2 (captured and
+episode, then an untimed pre-roll of at least 250 steps and 0.3 s), so any timed window -- also a 20-step
+one -- sees the steady-state fraction of grid-changing steps and about N/250 auto-resets per launch.  The K
+timed launches are 2 eager launches followed by ONE HIP-graph replay of the other K - 2 (captured and
 instantiated before the clock), inside the barrier / synchronize bracket, so a short window is
-kernel-bound, not host-launch-bound (--no-graph times eager launches only).
+kernel-bound, not host-launch-bound (--no-graph times eager launches only).  The whole W + K sequence is
+rehearsed once, untimed, before the measured pass: the first pass through the host launch paths costs tens
+of microseconds more than any later one (--no-rehearsal shows it; tools/window_variants.py measures it).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     -- HBM roofline of the dominant kernel from ALGORITHMIC bytes per env-step
@@ -59,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of one HIP-graph replay')
+    ap.add_argument('--no-rehearsal', action='store_true', help='skip the untimed rehearsal of the timed sequence')
     ap.add_argument('--lockstep', action='store_true',
                     help='skip the episode de-synchronisation (round-1 behaviour: all envs at the same episode step)')
     ap.add_argument('--mode', choices=['walking', 'flying'], default='walking',
@@ -299,41 +302,51 @@ def main():
         torch.cuda.current_stream(device).wait_stream(cap)
         graph.replay()  # part of the setup: the first launch of a graph also uploads it
         torch.cuda.synchronize(device)
-    # W untimed warm-up steps right before the clock (the chip is at its working clocks when timing starts); the
-    # counters are snapshotted on the device, not read, so nothing idles the GPU between warm-up and clock
     cur_h = env._stream()
-    for t in range(W):
-        step(t, cur_h)
-    st0_dev = env.stats_buf.sum(0)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()   # torch creates the HIP events lazily at their first record(): not inside the clock
-    ev1.record()
-    ev1.query()
-    gdist.barrier(device)
-    torch.cuda.synchronize(device)
-    ev0.record()   # the event window opens just before the wall clock and closes inside it
-    t_start = time.perf_counter()
-    t_a = time.perf_counter()
-    for t in range(W, W + head):
-        step(t, cur_h)
-    t_b = time.perf_counter()
-    if graph is not None:
-        graph.replay()
-    t_c = time.perf_counter()
-    ev1.record()
-    t_d = time.perf_counter()
-    while not ev1.query():  # spin: a blocking synchronize sleeps on an interrupt and wakes tens of microseconds late
-        pass
-    t_e = time.perf_counter()
-    torch.cuda.synchronize(device)
-    t_f = time.perf_counter()
-    gdist.barrier(device)
-    elapsed = time.perf_counter() - t_start
+
+    def window():
+        """W untimed warm-up steps, then the clock around exactly K steps.  Returns (wall seconds, counters before
+        the clock as a device tensor, host timeline)."""
+        # warm-up right before the clock; the counters are snapshotted on the device, not read, so nothing idles
+        # the GPU between warm-up and clock
+        for t in range(W):
+            step(t, cur_h)
+        before = env.stats_buf.sum(0)
+        ev0.record()   # torch creates the HIP events lazily at their first record(): not inside the clock
+        ev1.record()
+        ev1.query()
+        gdist.barrier(device)
+        torch.cuda.synchronize(device)
+        ev0.record()   # the event window opens just before the wall clock and closes inside it
+        t_start = time.perf_counter()
+        for t in range(W, W + head):
+            step(t, cur_h)
+        t_b = time.perf_counter()
+        if graph is not None:
+            graph.replay()
+        t_c = time.perf_counter()
+        ev1.record()
+        t_d = time.perf_counter()
+        while not ev1.query():  # spin: a blocking synchronize sleeps on an interrupt and wakes tens of us late
+            pass
+        t_e = time.perf_counter()
+        torch.cuda.synchronize(device)
+        t_f = time.perf_counter()
+        gdist.barrier(device)
+        t_end = time.perf_counter()
+        return t_end - t_start, before, (t_b - t_start, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e, t_end - t_f)
+
+    # One untimed rehearsal of the whole sequence first: the first pass through these host code paths (Python
+    # bytecode, ctypes thunks, the HIP runtime's launch and graph-launch paths) costs 30-60 us more than any later
+    # pass, which is 10 % of a 20-step window and nothing to do with the step kernel.  The rehearsal steps the
+    # envs like any other warm-up step; the measured pass below is a complete window of its own.
+    if not args.no_rehearsal:
+        window()
+    elapsed, st0_dev, host_tl = window()
     if os.environ.get('IGW_BENCH_TRACE'):
-        print('host us: - %.1f | head launches %.1f | graph launch %.1f | ev1.record %.1f | spin %.1f | '
-              'synchronize %.1f | barrier %.1f | total %.1f' % tuple(1e6 * x for x in (
-                  t_a - t_start, t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e,
-                  elapsed - (t_f - t_start), elapsed)), file=sys.stderr)
+        print('host us: head launches %.1f | graph launch %.1f | ev1.record %.1f | spin %.1f | synchronize %.1f | '
+              'barrier %.1f | total %.1f' % (tuple(1e6 * x for x in host_tl) + (1e6 * elapsed,)), file=sys.stderr)
     from gridworld_amd import _lib as _L
     s0 = st0_dev.cpu()
     st0 = {'changed': int(s0[_L.STAT_CHANGED]), 'resets': int(s0[_L.STAT_RESETS])}
@@ -389,7 +402,7 @@ def main():
                    'launches_per_step': 1,
                    'timed_as': 'eager launches' if graph is None else f'{head} eager launches + one HIP-graph replay of the other {K - head}',
                    'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + pre-roll)',
-                   'setup': 'untimed: task upload, pre-roll of >= 250 steps and >= 0.3 s with fresh random actions (steady state, clock ramp), graph capture + one replay, then the W warm-up steps',
+                   'setup': 'untimed: task upload, pre-roll of >= 250 steps and >= 0.3 s with fresh random actions (steady state, clock ramp), graph capture + one replay, one untimed rehearsal of the W + K sequence (host code paths warm), then the W warm-up steps and the clock',
                    'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
