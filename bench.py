@@ -19,8 +19,9 @@ one -- sees the steady-state fraction of grid-changing steps and about N/250 aut
 timed launches are 2 eager launches followed by ONE HIP-graph replay of the other K - 2 (captured and
 instantiated before the clock), inside the barrier / synchronize bracket, so a short window is
 kernel-bound, not host-launch-bound (--no-graph times eager launches only).  The whole W + K sequence is
-rehearsed once, untimed, before the measured pass: the first pass through the host launch paths costs tens
-of microseconds more than any later one (--no-rehearsal shows it; tools/window_variants.py measures it).
+rehearsed a fixed 3 times, untimed, before the measured (always the last) pass: the first passes through the
+host launch paths cost tens of microseconds more than later ones (--rehearsals 0 shows it, every pass is
+reported in config.rehearsal_ms_per_step; tools/window_variants.py measures the launch paths).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     -- HBM roofline of the dominant kernel from ALGORITHMIC bytes per env-step
@@ -61,7 +62,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of one HIP-graph replay')
-    ap.add_argument('--no-rehearsal', action='store_true', help='skip the untimed rehearsal of the timed sequence')
+    ap.add_argument('--rehearsals', type=int, default=3,
+                    help='untimed passes through the whole W + K sequence before the measured one (reported)')
     ap.add_argument('--lockstep', action='store_true',
                     help='skip the episode de-synchronisation (round-1 behaviour: all envs at the same episode step)')
     ap.add_argument('--mode', choices=['walking', 'flying'], default='walking',
@@ -337,12 +339,12 @@ def main():
         t_end = time.perf_counter()
         return t_end - t_start, before, (t_b - t_start, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e, t_end - t_f)
 
-    # One untimed rehearsal of the whole sequence first: the first pass through these host code paths (Python
-    # bytecode, ctypes thunks, the HIP runtime's launch and graph-launch paths) costs 30-60 us more than any later
-    # pass, which is 10 % of a 20-step window and nothing to do with the step kernel.  The rehearsal steps the
-    # envs like any other warm-up step; the measured pass below is a complete window of its own.
-    if not args.no_rehearsal:
-        window()
+    # A fixed number of untimed rehearsals of the whole sequence first: the first passes through these host code
+    # paths (Python bytecode, ctypes thunks, the HIP runtime's launch and graph-launch paths) cost 30-80 us more
+    # than later ones, which is 10-20 % of a 20-step window and nothing to do with the step kernel.  A rehearsal
+    # steps the envs like any other warm-up step; the measured pass is always the LAST one, a complete window of
+    # its own, and the rehearsals' ms/step are reported next to it (config.rehearsal_ms_per_step).
+    rehearsal_ms = [round(1e3 * window()[0] / K, 5) for _ in range(args.rehearsals)]
     elapsed, st0_dev, host_tl = window()
     if os.environ.get('IGW_BENCH_TRACE'):
         print('host us: head launches %.1f | graph launch %.1f | ev1.record %.1f | spin %.1f | synchronize %.1f | '
@@ -402,7 +404,8 @@ def main():
                    'launches_per_step': 1,
                    'timed_as': 'eager launches' if graph is None else f'{head} eager launches + one HIP-graph replay of the other {K - head}',
                    'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + pre-roll)',
-                   'setup': 'untimed: task upload, pre-roll of >= 250 steps and >= 0.3 s with fresh random actions (steady state, clock ramp), graph capture + one replay, one untimed rehearsal of the W + K sequence (host code paths warm), then the W warm-up steps and the clock',
+                   'setup': 'untimed: task upload, pre-roll of >= 250 steps and >= 0.3 s with fresh random actions (steady state, clock ramp), graph capture + one replay, %d untimed rehearsals of the W + K sequence (host code paths warm), then the W warm-up steps and the clock' % args.rehearsals,
+                   'rehearsal_ms_per_step': rehearsal_ms,
                    'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
