@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
+    ap.add_argument('--no-async', action='store_true', help='skip the secondary two-sub-batch measurement')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of one HIP-graph replay')
     ap.add_argument('--rehearsals', type=int, default=3,
                     help='untimed passes through the whole W + K sequence before the measured one (reported)')
@@ -371,6 +372,31 @@ def main():
         f_steps, f_el = gdist.reduce_window(N * Tf, time.perf_counter() - t0, device)
         fused = f_steps / f_el
 
+    # secondary: the same kernel as two independent sub-batches on two HIP streams (VecGridWorld.split, the
+    # EnvPool-style asynchronous mode): no barrier between the halves, so the start of one half's next step
+    # fills the end of the other's -- what one launch per step over the whole batch cannot do
+    async2 = None
+    if not args.no_async and not flying and N % 2 == 0:
+        subs = env.split(2)
+        jobs = [(sb.ctx, ctypes.c_void_p(sb.stream.cuda_stream), 4 * sb.lo) for sb in subs]
+        Ka = min(K, W + K)
+        torch.cuda.synchronize(device)
+        for timed in (False, True):
+            gdist.barrier(device)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for t in range(Ka):
+                for ctx_s, st_s, off in jobs:
+                    rc = walk_fn(ctx_s, wptrs[t] + off, st_s)
+                    if rc:
+                        L.check(rc, 'igw_step_walking')
+            torch.cuda.synchronize(device)
+            gdist.barrier(device)
+            a_el = time.perf_counter() - t0
+        a_steps, a_el = gdist.reduce_window(N * Ka, a_el, device)
+        async2 = a_steps / a_el
+        del subs
+
     if rank != 0:
         return
     lanes = env.cfg.lanes_per_env or auto_lanes(N)
@@ -407,7 +433,8 @@ def main():
                    'setup': 'untimed: task upload, pre-roll of >= 250 steps and >= 0.3 s with fresh random actions (steady state, clock ramp), graph capture + one replay, %d untimed rehearsals of the W + K sequence (host code paths warm), then the W warm-up steps and the clock' % args.rehearsals,
                    'rehearsal_ms_per_step': rehearsal_ms,
                    'resets_in_window': resets, 'p_changed': p,
-                   'fused_rollout_env_steps_per_s': fused},
+                   'fused_rollout_env_steps_per_s': fused,
+                   'async_2_subbatches_env_steps_per_s': async2},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': hbm_bytes,
                      'kernel': 'igw::step_kernel<%d, %d, false>' % (lanes, 1 if flying else 0), 'kernel_avg_ms': kernel_ms,

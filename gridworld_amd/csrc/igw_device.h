@@ -26,15 +26,21 @@ constexpr int WAVE = 64;
 // point 0 = lowest digit).  The SIMD arbitrates issue by priority first and wave age second.  With age alone the
 // four co-resident waves of a SIMD run one behind the other and the launch ends with the youngest wave running its
 // last phases alone, latency-bound; with "the wave that is behind goes first" all four reach the end together and
-// the SIMD stays issue-bound to the end (-9 % launch time, same-box A/B).  Points: 0 start, 1 inputs loaded,
+// the SIMD stays issue-bound to the end (-9 % launch time, same-box A/B).  `boost`: one level up for a wave that
+// knows it has an episode reset to do at the end of the step (-1 %; boosting waves with several changed envs
+// measured +1 %).  Points: 0 start, 1 inputs loaded,
 // 2 ray march: coordinates done, 3 place / break done, 4 first physics sub-step done, 5 physics done,
 // 6 histogram update done, 7 resets done.
 #ifndef IGW_PRIO_MAP
 #define IGW_PRIO_MAP 0x00112233
 #endif
 template <bool ON, int PT>
-__device__ inline void prio_at() {
-    if constexpr (ON) __builtin_amdgcn_s_setprio((IGW_PRIO_MAP >> (4 * PT)) & 3);
+__device__ inline void prio_at(bool boost = false) {
+    if constexpr (ON) {
+        constexpr int level = (IGW_PRIO_MAP >> (4 * PT)) & 3;
+        if (boost) __builtin_amdgcn_s_setprio(level < 3 ? level + 1 : 3);
+        else __builtin_amdgcn_s_setprio(level);
+    }
 }
 #ifndef IGW_BLOCK
 #define IGW_BLOCK 256
@@ -511,7 +517,7 @@ __device__ inline void key_unpack(int key, int& x, int& y, int& z) {
 // rounding of every partial sum is reproduced).
 template <int GS, bool PRIO = false>
 __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x, double y, double z,
-                               double vx, double vy, double vz) {
+                               double vx, double vy, double vz, bool boost = false) {
     constexpr int SAMPLES = 40;  // max_distance 8 * m 5
     const double sx = div5(vx), sy = div5(vy), sz = div5(vz);  // dx / m with m = 5
     Hit h;
@@ -564,7 +570,7 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
             key[r] = (int)__builtin_amdgcn_perm(wz, __builtin_amdgcn_perm(wy, wx, sel_xy), sel_z);
             word[r] = occ_s[key_idx(key[r]) >> 5];  // all probes are issued before the first is consumed
         }
-        prio_at<PRIO, 2>();
+        prio_at<PRIO, 2>(boost);
         // `key != previous and key in world`, first sample wins: every lane scans its own samples (previous =
         // the neighbouring lane's key of the same round, or lane 3's key of the round before); sample number
         // and key share one word, so one group minimum yields the earliest candidate and its key.

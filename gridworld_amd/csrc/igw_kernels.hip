@@ -288,7 +288,8 @@ struct Motion {  // get_motion_vector (core/world.py:163-201): constant over the
 template <int GS, int MODE, bool PRIO = false>
 __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
                                        const int8_t* grid_g, const TrigCtx& trig, double s0, double s1, double dy,
-                                       int inventory, double cam0, double cam1, bool remove, bool add, Motion& mv) {
+                                       int inventory, double cam0, double cam1, bool remove, bool add, Motion& mv,
+                                       bool boost = false) {
     constexpr bool FLY = MODE == MODE_FLY;
     CellChange ch;
     ch.idx = -1; ch.bit = 0; ch.old_val = 0; ch.new_val = 0;
@@ -353,7 +354,7 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
     if (want_sight) {
         // m = cos(radians(y)); dy = sin(radians(y)); dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
         const double vx = cy * cp, vy = sp, vz = sy * cp;
-        const Hit h = hit_test<GS, PRIO>(G, occ_s, e.x, e.y, e.z, vx, vy, vz);
+        const Hit h = hit_test<GS, PRIO>(G, occ_s, e.x, e.y, e.z, vx, vy, vz, boost);
         if (add) {
             if (h.hit && h.have_prev) {
                 if (inv_get(e.inv, e.active - 1) > 0 && build_zone_i(h.px, h.py, h.pz)) {
@@ -408,13 +409,13 @@ __device__ inline void finish_break(Env& e, const CellChange& ch) {
 // World.step second half: update(dt = 1/20) (core/world.py:203-262) and the yaw wrap (:451-456)
 template <int GS, int MODE, bool PRIO = false>
 __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, const uint32_t* occ_s,
-                                    const Motion& mv) {
+                                    const Motion& mv, bool boost = false) {
     constexpr bool FLY = MODE == MODE_FLY;
     const int m = e.tis;
     const double dt = m == 2 ? 0.05 / 2 : m == 4 ? 0.05 / 4 : m == 8 ? 0.05 / 8 : 0.05 / 12;
     [[maybe_unused]] double vy_pre = 0.0;
     for (int i = 0; i < (IGW_DIAG_FLAG(p, 4) ? 0 : m); i++) {  // _update, :222-262
-        if (i == 1) prio_at<PRIO, 4>();
+        if (i == 1) prio_at<PRIO, 4>(boost);
         const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
         const double d = dt * speed;
         const double ddx = mv.x * d, ddz = mv.z * d;
@@ -904,7 +905,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         meta_touch = p.task_meta[task].target_size;
     wave_sync();
     stamp(p, 1);
-    prio_at<true, 1>();
+    // a wave with an episode running out in this step has the reset to do on top: one priority level up
+    const bool boost = __any(p.autoreset && e.step_no + 1 >= p.max_steps);
+    prio_at<true, 1>(boost);
     [[maybe_unused]] const int diag_m = e.tis;  // IGW_DIAG: sub-steps this env asked for
     e.step_no = min(e.step_no + 1, 65535);  // env.py:276
     CellChange ch;
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     if (MODE == MODE_WALK) {
         const WalkAct w = parse_walking_discrete(ra.action);
         ch = world_act<GS, MODE_WALK, true>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
-                                      w.remove, w.add, mv);
+                                      w.remove, w.add, mv, boost);
     } else if (MODE == MODE_WALK_DICT) {  // parse_walking_action, core/world.py:396-414
         const uint2 bw = ra.buttons;
         const bool fwd = bw.x & 0xffu, back = bw.x & 0xff00u, left = bw.x & 0xff0000u, right = bw.x & 0xff000000u;
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
         const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
         ch = world_act<GS, MODE_WALK_DICT, true>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
-                                           attack, use, mv);
+                                           attack, use, mv, boost);
     } else {  // parse_flying_action, core/world.py:416-432
         const int placement = ra.placement;
         int inventory = ra.inventory;
@@ -941,23 +944,23 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         }
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
         ch = world_act<GS, MODE_FLY, true>(G, p, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
-                                     placement == 2, placement == 1, mv);
+                                     placement == 2, placement == 1, mv, boost);
     }
     // issued here, consumed after the histogram update
     int start_val = 0, env_max_int = 0;
     if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
     if (p.size_reward && e.step_no == 1) env_max_int = p.task_meta[task].env_max_int;
     stamp(p, 2);
-    prio_at<true, 3>();
     const bool changed = active && ch.idx >= 0 && !IGW_DIAG_FLAG(p, 1);
     // the histogram row, target level, start byte and bounding boxes of every changed env start moving into
     // LDS now and land while the physics runs
     const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env_r, task, ch);
-    if (MODE == MODE_FLY) world_update<GS, MODE_FLY, true>(G, p, e, occ_s, mv);
-    else world_update<GS, MODE_WALK, true>(G, p, e, occ_s, mv);
+    prio_at<true, 3>(boost);
+    if (MODE == MODE_FLY) world_update<GS, MODE_FLY, true>(G, p, e, occ_s, mv, boost);
+    else world_update<GS, MODE_WALK, true>(G, p, e, occ_s, mv, boost);
     finish_break(e, ch);
     stamp(p, 3);
-    prio_at<true, 5>();
+    prio_at<true, 5>(boost);
     // Everything fetched early (break colour, start byte, the DMA of the changed envs) has to be in by now; the
     // physics had the time of its sub-steps to cover it.
     if (chg_mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         }
     }
     stamp(p, 5);
-    prio_at<true, 6>();
+    prio_at<true, 6>(boost);
     const StepOut o = finish_step(p, e, env_max_int, size_new, mi);
     const bool do_reset = active && o.done && p.autoreset;
     uint32_t ep = 0;
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     }
     resolve_resets<GS, EXTRA>(G, p, do_reset, env, task, has_start, ep, nullptr,
                               reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
-    prio_at<true, 7>();
+    prio_at<true, 7>(boost);
 #ifdef IGW_DIAG
     {
         const unsigned long long n_ch = __builtin_popcountll(__ballot(changed && G.gl == 0));

@@ -24,9 +24,10 @@ for f in bench_default bench_20 bench_flying bench_1m bench_gs2 bench_gs8; do
 import json, sys
 try:
     d = json.loads(open(sys.argv[1] + '.json').read().strip().splitlines()[-1])
-    print('%-28s %.3f G  ms/step %.4f  kernel %.4f ms  frac %.3f  resets %s  p %.4f  fused %s' % (
+    print('%-28s %.3f G  ms/step %.4f  kernel %.4f ms  frac %.3f  resets %s  p %.4f  fused %s  async2 %s' % (
         sys.argv[1].split('/')[-1], d['value'] / 1e9, d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['roofline']['frac'],
-        d['config']['resets_in_window'], d['config']['p_changed'], d['config']['fused_rollout_env_steps_per_s']))
+        d['config']['resets_in_window'], d['config']['p_changed'], d['config']['fused_rollout_env_steps_per_s'],
+        d['config'].get('async_2_subbatches_env_steps_per_s')))
 except Exception as e:
     print(sys.argv[1], 'ERR', e, open(sys.argv[1] + '.err').read()[-800:])
 PY
