@@ -298,6 +298,39 @@ def test_single_colour_floors_vs_oracle(gs):
     _check_occ(env)
 
 
+@pytest.mark.parametrize('gs', [0, 8, 4, 2, 1])
+def test_every_env_of_a_wave_changes_in_the_same_step(gs):
+    """All envs get the same scripted action, so every env of a wave places / breaks in the same step: the
+    histogram update runs out of scratch rows (first chunk), uses the rows prefetched into the dead occupancy
+    rows (second chunk) and then the fetch-now path (later chunks).  Per-env rt20 targets; oracle at every
+    step, then a fresh recount of the persistent histogram and the occupancy bitmap."""
+    from gridworld_amd import VecGridWorld
+    from oracle import oracle as O
+    n = 200  # ragged: the last wave is partly filled
+    tg = _rt20_targets(n, 21)
+    kw = dict(size_reward=False, max_steps=1000)
+    env = VecGridWorld(n, autoreset=False, lanes_per_env=gs, **kw)
+    env.set_tasks(tg)
+    env.reset()
+    ob = O.OracleBatch(n, **kw)
+    ob.set_tasks(tg)
+    ob.reset()
+    script = [14] * 8
+    for rep in range(12):
+        script += [17, 6 + rep % 6, 17, 1 + rep % 4, 17, 16, 12, 17, 16, 16, 5, 17, 3, 17, 13, 16]
+    changes = 0
+    for t, a in enumerate(script):
+        acts = np.full(n, a, np.int32)
+        before = env.stats()['rescans']
+        env.step(torch.as_tensor(acts))
+        ob.step_walking(acts, nthreads=8)
+        _compare(env, ob, f'step {t} (action {a})')
+        changes += env.stats()['rescans'] - before == n
+    assert changes >= 20, 'the script should make every env change its grid in the same step many times'
+    _check_hist(env, tg, sample=range(0, n, 2))
+    _check_occ(env)
+
+
 def test_product_does_not_import_oracle():
     import sys
     import gridworld_amd  # noqa: F401

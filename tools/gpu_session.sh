@@ -14,7 +14,7 @@ timeout 300 python3 bench.py --mode flying --no-cpu-baseline > $D/bench_flying.j
 timeout 300 python3 tools/stamp_phases.py $D/stamps.npz 4 > $D/stamps.txt 2>&1
 timeout 300 python3 tools/stamp_phases.py $D/stamps_nodrain.npz 4 8 > $D/stamps_nodrain.txt 2>&1
 if [ "$MODE" = "full" ]; then
-  timeout 300 python3 bench.py --lanes-per-env 1 --envs-per-gpu 1048576 --steps 50 --no-cpu-baseline --no-fused > $D/bench_1m.json 2> $D/bench_1m.err
+  timeout 300 python3 bench.py --envs-per-gpu 1048576 --steps 50 --no-cpu-baseline --no-fused > $D/bench_1m.json 2> $D/bench_1m.err
   timeout 300 python3 bench.py --lanes-per-env 2 --no-cpu-baseline --no-fused > $D/bench_gs2.json 2> $D/bench_gs2.err
   timeout 300 python3 bench.py --lanes-per-env 8 --no-cpu-baseline --no-fused > $D/bench_gs8.json 2> $D/bench_gs8.err
   timeout 1200 bash tools/profile_gpu.sh $TAG > $D/profile.txt 2>&1
