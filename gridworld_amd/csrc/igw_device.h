@@ -298,11 +298,15 @@ __device__ inline void env_load(Env& e, const AgentRec* rec) {
 }
 // The record is stored in two parts: the pose (bytes 0..47) is final as soon as the physics has run, the
 // counters (bytes 48..63) only after the reward tail.
+typedef double vd2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long vu2 __attribute__((ext_vector_type(2)));
+// Per-step outputs are written once and next read by another launch: non-temporal stores (-1 % launch time).
+template <class T> __device__ inline void st(T* p, T v) { __builtin_nontemporal_store(v, p); }
 __device__ inline void env_store_pose(const Env& e, AgentRec* rec) {
-    double2* d = reinterpret_cast<double2*>(rec);
-    d[0] = make_double2(e.x, e.y);
-    d[1] = make_double2(e.z, e.yaw);
-    d[2] = make_double2(e.pitch, e.vy);
+    vd2* d = reinterpret_cast<vd2*>(rec);
+    st(d + 0, vd2{e.x, e.y});
+    st(d + 1, vd2{e.z, e.yaw});
+    st(d + 2, vd2{e.pitch, e.vy});
 }
 __device__ inline void env_store_counters(const Env& e, AgentRec* rec) {
     const uint64_t lo = (uint64_t)(uint16_t)e.step_no | ((uint64_t)(uint16_t)(int16_t)e.size << 16) |
@@ -310,7 +314,7 @@ __device__ inline void env_store_counters(const Env& e, AgentRec* rec) {
                         ((uint64_t)(uint16_t)(int16_t)e.max_int << 48);
     const uint64_t code = e.tis == 2 ? 0 : e.tis == 4 ? 1 : e.tis == 8 ? 2 : 3;
     const uint64_t hi = e.inv | (code << 48) | ((uint64_t)(e.active & 7) << 50) | ((uint64_t)(e.target_size & 0x7ff) << 53);
-    reinterpret_cast<ulonglong2*>(rec)[3] = make_ulonglong2(lo, hi);
+    st(reinterpret_cast<vu2*>(rec) + 3, vu2{lo, hi});
 }
 __device__ inline void env_store(const Env& e, AgentRec* rec) {
     env_store_pose(e, rec);

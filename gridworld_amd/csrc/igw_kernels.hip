@@ -261,11 +261,11 @@ __device__ inline void write_reset_obs(const KParams& p, int env, const Env& e) 
 // obs of step(): env.py:281-289
 __device__ inline void write_step_obs(const KParams& p, int env, const Env& e) {
     float* ap = p.agent_pos + 5 * (size_t)env;
-    ap[0] = (float)e.x; ap[1] = (float)e.y; ap[2] = (float)e.z; ap[3] = (float)e.pitch; ap[4] = (float)e.yaw;
+    st(ap + 0, (float)e.x); st(ap + 1, (float)e.y); st(ap + 2, (float)e.z); st(ap + 3, (float)e.pitch); st(ap + 4, (float)e.yaw);
     float* iv = p.inventory + 6 * (size_t)env;
 #pragma unroll
-    for (int i = 0; i < 6; i++) iv[i] = (float)inv_get(e.inv, i);
-    p.compass[env] = (float)(e.yaw - 180.0);
+    for (int i = 0; i < 6; i++) st(iv + i, (float)inv_get(e.inv, i));
+    st(p.compass + env, (float)(e.yaw - 180.0));
 }
 
 struct CellChange {
@@ -881,6 +881,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
     if (wave_env0 >= p.n_envs) return;
+    if (IGW_DIAG_FLAG(p, 64)) return;  // diag 64: the empty launch (same grid, registers and LDS)
     stamp(p, 0);
     prio_at<true, 0>();
     // Lanes past the last env (only in the last wave, when N is not a multiple of the envs per wave) run on a copy
@@ -905,6 +906,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         meta_touch = p.task_meta[task].target_size;
     wave_sync();
     stamp(p, 1);
+    if (IGW_DIAG_FLAG(p, 128)) return;  // diag 128: launch + the input burst, nothing else
     // a wave with an episode running out in this step has the reset to do on top: one priority level up
     const bool boost = __any(p.autoreset && e.step_no + 1 >= p.max_steps);
     prio_at<true, 1>(boost);
@@ -964,6 +966,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     // Everything fetched early (break colour, start byte, the DMA of the changed envs) has to be in by now; the
     // physics had the time of its sub-steps to cover it.
     if (chg_mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and counts as consumed HERE: the counter is in order over loads and stores, so a first use at the end of
+    // the step would wait for every store issued from now on (observations, histogram pieces) as well
+    asm volatile("" : "+v"(start_val), "+v"(env_max_int));
     // Pose and observations are final: their stores are issued here -- behind that wait, so it does not wait for
     // them -- and complete in the shadow of the histogram update's LDS round trips, not at the very end of the
     // wave.  (A reset at the end of this step overwrites them: same lane, same addresses, program order.)
@@ -1023,8 +1028,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
             p.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = occ_s[OCC_VAR0 + (ch.bit >> 5)];
         }
         if (!IGW_DIAG_FLAG(p, 16)) {  // diag 16: what the output stores cost
-            p.reward[env] = (float)o.reward;
-            p.done[env] = o.done ? 1 : 0;
+            st(p.reward + env, (float)o.reward);
+            st(p.done + env, (uint8_t)(o.done ? 1 : 0));
             if (do_reset) write_reset_obs(p, env, e);
         }
         if (do_reset) env_store_pose(e, p.agent + env);
