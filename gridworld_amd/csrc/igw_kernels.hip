@@ -586,7 +586,28 @@ struct RawAct {
     uint2 buttons;              // walking Dict
     float f[5];                 // flying movement[3] + camera[2]; walking Dict camera in f[3], f[4]
     int32_t inventory, placement;
+    uint32_t w1, w2;            // flying, groups of 4+ lanes: the seven dwords spread over the lanes of a quad
 };
+// Flying action of an env in groups of 4+ lanes: two loads instead of seven -- lane q of a quad fetches movement[q]
+// (q < 3) or camera[0], then camera[1] / inventory / placement; fly_fields() hands them round by DPP at the use.
+template <int GS>
+__device__ inline void load_fly_spread(const ActIn& a, int env, int gl, RawAct& r) {
+    const int q = gl & 3;
+    const void* p1 = q < 3 ? (const void*)(a.movement + 3 * (size_t)env + q) : (const void*)(a.camera + 2 * (size_t)env);
+    const void* p2 = q == 0 ? (const void*)(a.camera + 2 * (size_t)env + 1)
+                   : q == 1 ? (const void*)(a.inventory + env) : (const void*)(a.placement + env);
+    r.w1 = *reinterpret_cast<const uint32_t*>(p1);
+    r.w2 = *reinterpret_cast<const uint32_t*>(p2);
+}
+__device__ inline void fly_fields(RawAct& r) {
+    r.f[0] = __uint_as_float((uint32_t)dpp_quad<QUAD_BCAST0>((int)r.w1));
+    r.f[1] = __uint_as_float((uint32_t)dpp_quad<QUAD_BCAST1>((int)r.w1));
+    r.f[2] = __uint_as_float((uint32_t)dpp_quad<QUAD_BCAST2>((int)r.w1));
+    r.f[3] = __uint_as_float((uint32_t)dpp_quad<QUAD_BCAST3>((int)r.w1));
+    r.f[4] = __uint_as_float((uint32_t)dpp_quad<QUAD_BCAST0>((int)r.w2));
+    r.inventory = dpp_quad<QUAD_BCAST1>((int)r.w2);
+    r.placement = dpp_quad<QUAD_BCAST2>((int)r.w2);
+}
 template <int MODE>
 __device__ inline RawAct load_action(const ActIn& a, int env) {
     RawAct r = {};
@@ -895,7 +916,10 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     int8_t* grid_g = p.grid + (size_t)env_r * STRIDE;
     int task = p.env_task[env_r];
     const AgentRec rec = p.agent[env_r];  // every lane of the group reads the same 64 B line (one request)
-    const RawAct ra = load_action<MODE>(a, env_r);
+    constexpr bool FLY_SPREAD = MODE == MODE_FLY && GS >= 4;
+    RawAct ra = {};
+    if constexpr (FLY_SPREAD) load_fly_spread<GS>(a, env_r, G.gl, ra);
+    else ra = load_action<MODE>(a, env_r);
     occ_commit<GS>(G, occ_in, occ_s, occ_wave_s);
     Env e;
     env_unpack(e, rec);
@@ -935,6 +959,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         ch = world_act<GS, MODE_WALK_DICT, true>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
                                            attack, use, mv, boost);
     } else {  // parse_flying_action, core/world.py:416-432
+        if constexpr (FLY_SPREAD) fly_fields(ra);
         const int placement = ra.placement;
         int inventory = ra.inventory;
         double f[5] = {(double)ra.f[0], (double)ra.f[1], (double)ra.f[2], (double)ra.f[3], (double)ra.f[4]};

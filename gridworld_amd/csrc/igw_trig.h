@@ -6,9 +6,10 @@
 //
 // Method: double-double evaluation, then round.
 //   sincos: Cody-Waite reduction by pi/2 (triple-double, exact products via fma), table of
-//           sin/cos(j/64) in double-double, degree-9/8 Taylor tails on |d| <= 1/128 with the
-//           leading correction terms in double-double.
-//   atan2 : ratio in double-double, table of atan(j/64), atan(u) series on |u| <= 1/128.
+//           sin/cos(j/256) in double-double, degree-9/8 Taylor tails on |d| <= 1/512 with the
+//           leading correction terms in double-double; a quick evaluation with an error bound first
+//           (Ziv's strategy), the full double-double one only when the bound straddles a rounding boundary.
+//   atan2 : ratio in double-double, table of atan(j/256), atan(u) series on |u| <= 1/512; quick evaluation first.
 // The double-double result carries ~100 bits, so the returned double is the correctly rounded
 // value except for astronomically rare ties-at-100-bits; on 2*10^5 random arguments each function
 // matches mpmath's correctly rounded result everywhere (tests/test_trig.py).  glibc 2.35 (what the
@@ -81,33 +82,43 @@ IGW_HD dd_t dd_div(dd_t a, dd_t b) {
     return dd_add_d(q, q3);
 }
 
-// sin and cos of x (radians), |x| < 2^20
-IGW_HD void igw_sincos(double x, double* s_out, double* c_out) {
+// Argument reduction shared by the two evaluations below: x = kd * pi/2 + r, |r| <= pi/4 (+ a rounding sliver),
+// r as a double-double.
+IGW_HD dd_t sincos_reduce(double x, double* kd_out) {
     using namespace trigtab;
-    if (x == 0.0) {
-        *s_out = x;  // keeps the sign of zero
-        *c_out = 1.0;
-        return;
-    }
-    // reduction: r = x - k * pi/2, |r| <= pi/4 (+ a rounding sliver)
     const double kd = __builtin_rint(x * TWO_OVER_PI);
-    dd_t r;
-    if (kd == 0.0) {
-        r = dd_t{x, 0.0};
-    } else {
-        const dd_t p1 = dd_two_prod(kd, PIO2_1);
-        const double r0 = x - p1.hi;  // exact (Sterbenz)
-        r = dd_two_sum(r0, -p1.lo);
-        const dd_t p2 = dd_two_prod(kd, PIO2_2);
-        r = dd_add(r, dd_neg(p2));
-        r = dd_add_d(r, -(kd * PIO2_3));
-    }
+    *kd_out = kd;
+    if (kd == 0.0) return dd_t{x, 0.0};
+    const dd_t p1 = dd_two_prod(kd, PIO2_1);
+    const double r0 = x - p1.hi;  // exact (Sterbenz)
+    dd_t r = dd_two_sum(r0, -p1.lo);
+    const dd_t p2 = dd_two_prod(kd, PIO2_2);
+    r = dd_add(r, dd_neg(p2));
+    return dd_add_d(r, -(kd * PIO2_3));
+}
+IGW_HD void sincos_quadrant(double kd, double sr, double cr, double* s_out, double* c_out) {
+    const long long k = (long long)kd;
+    const int n = (int)(((k % 4) + 4) % 4);
+    double sn, cs;
+    if (n == 0) { sn = sr; cs = cr; }
+    else if (n == 1) { sn = cr; cs = -sr; }
+    else if (n == 2) { sn = -sr; cs = -cr; }
+    else { sn = -cr; cs = sr; }
+    *s_out = sn;
+    *c_out = cs;
+}
+
+// The accurate evaluation: everything in double-double (~100 bits), then round.
+IGW_HD void igw_sincos_accurate(double x, double* s_out, double* c_out) {
+    using namespace trigtab;
+    double kd;
+    dd_t r = sincos_reduce(x, &kd);
     const bool neg = r.hi < 0.0;
     if (neg) r = dd_neg(r);
-    // table point j/64 and remainder d, |d| <= 1/128
-    const double jd = __builtin_rint(r.hi * 64.0);
+    // table point j/256 and remainder d, |d| <= 1/512
+    const double jd = __builtin_rint(r.hi * 256.0);
     const int j = (int)jd;
-    const dd_t d = dd_two_sum(r.hi - jd * 0.015625, r.lo);
+    const dd_t d = dd_two_sum(r.hi - jd * 0.00390625, r.lo);
     const dd_t S = dd_t{SINCOS[j][0], SINCOS[j][1]};
     const dd_t C = dd_t{SINCOS[j][2], SINCOS[j][3]};
     const dd_t d2 = dd_mul(d, d);
@@ -125,23 +136,77 @@ IGW_HD void igw_sincos(double x, double* s_out, double* c_out) {
     dd_t sr = dd_add(S, dd_add(dd_mul(C, sind), dd_mul(S, cm1)));
     const dd_t cr = dd_add(C, dd_add(dd_mul(C, cm1), dd_neg(dd_mul(S, sind))));
     if (neg) sr = dd_neg(sr);
-    const long long k = (long long)kd;
-    const int n = (int)(((k % 4) + 4) % 4);
-    double sn, cs;
-    if (n == 0) { sn = sr.hi; cs = cr.hi; }
-    else if (n == 1) { sn = cr.hi; cs = -sr.hi; }
-    else if (n == 2) { sn = -sr.hi; cs = -cr.hi; }
-    else { sn = -cr.hi; cs = sr.hi; }
-    *s_out = sn;
-    *c_out = cs;
+    sincos_quadrant(kd, sr.hi, cr.hi, s_out, c_out);
 }
 
-// atan2(y, x) for finite arguments
-IGW_HD double igw_atan2(double y, double x) {
+// The quick evaluation (Ziv's strategy): the same reduction and table, but only the leading products exact
+// (two_prod) and everything small in plain double -- about a third of the flops -- as a value hi + lo with an
+// error bound E; the result is final when hi + (lo - E) and hi + (lo + E) round to the same double, which they do
+// except on about one argument in 2^19.  Returns false otherwise (the caller then runs the accurate evaluation).
+// Error budget, absolute, |d| <= 2^-9.  Table points j >= 1 (results >= 2^-9 in magnitude): the largest plain-
+// double tail is C (sin d - d), <= 2^-29.6; it is computed with a relative error <= 5 * 2^-53 (coefficient, q,
+// three products, one sum): 2^-80.3; the five sums that contain it add <= 2^-82.6 each; the dropped series terms
+// (d^9/9!, d^8/8!) are < 2^-87.  Total < 2^-79; E = 2^-76.  j == 0 (sin x ~ x, possibly tiny): every tail scales
+// with d^3, the error is < 2^-71 |d|; E = 2^-68 |d|.  tests/test_trig.py: no wrong acceptance, and none with
+// E / 16 either.
+IGW_HD bool igw_sincos_quick(double x, double* s_out, double* c_out) {
+    using namespace trigtab;
+    double kd;
+    dd_t r = sincos_reduce(x, &kd);
+    const bool neg = r.hi < 0.0;
+    if (neg) r = dd_neg(r);
+    const double jd = __builtin_rint(r.hi * 256.0);
+    const int j = (int)jd;
+    const dd_t d = dd_two_sum(r.hi - jd * 0.00390625, r.lo);
+    const double dh = d.hi, dl = d.lo;
+    const double Sh = SINCOS[j][0], Sl = SINCOS[j][1], Ch = SINCOS[j][2], Cl = SINCOS[j][3];
+    const dd_t d2 = dd_two_prod(dh, dh);  // dh^2 exactly
+    const double q = d2.hi;
+    // sin d = dh + ts:  ts = dl (1 - q/2) + dh^3 (-1/6 + q/120 - q^2/5040)
+    const double ps = (q * dh) * (-0x1.5555555555555p-3 + q * (0x1.1111111111111p-7 + q * -0x1.a01a01a01a01ap-13));
+    const double ts = (dl - 0.5 * q * dl) + ps;
+    // cos d - 1 = ch + tc:  ch = -dh^2/2 (hi part, exact), tc = -d2.lo/2 - dh dl + d^4 (1/24 - q/720)
+    const double pc = (q * q) * (0x1.5555555555555p-5 + q * -0x1.6c16c16c16c17p-10);
+    const double ch = -0.5 * d2.hi;
+    const double tc = (pc - dh * dl) - 0.5 * d2.lo;
+    // sin(xj + d) = S + C sin d + S (cos d - 1)
+    const dd_t p1 = dd_two_prod(Ch, dh), p2 = dd_two_prod(Sh, ch);
+    dd_t a = dd_fast_two_sum(Sh, p1.hi);   // |Sh| >= |Ch dh| for j >= 1; Sh == 0 for j == 0
+    dd_t b = dd_fast_two_sum(a.hi, p2.hi);
+    double s_hi = b.hi;
+    double s_lo = (((Ch * ts + Cl * dh) + (Sh * tc + Sl * ch)) + ((p1.lo + p2.lo) + Sl)) + (a.lo + b.lo);
+    // cos(xj + d) = C + C (cos d - 1) - S sin d
+    const dd_t p3 = dd_two_prod(Ch, ch), p4 = dd_two_prod(Sh, dh);
+    a = dd_fast_two_sum(Ch, -p4.hi);       // Ch >= 0.7 > |Sh dh|
+    b = dd_fast_two_sum(a.hi, p3.hi);
+    const double c_hi = b.hi;
+    const double c_lo = (((Ch * tc + Cl * ch) - (Sh * ts + Sl * dh)) + ((p3.lo - p4.lo) + Cl)) + (a.lo + b.lo);
+    if (neg) { s_hi = -s_hi; s_lo = -s_lo; }
+#ifndef IGW_QUICK_E_SCALE   // tests only: shrink E to find where the first wrong acceptance appears (the margin)
+#define IGW_QUICK_E_SCALE 1.0
+#endif
+    const double es = (j == 0 ? 0x1p-68 * dh : 0x1p-76) * IGW_QUICK_E_SCALE, ec = 0x1p-76 * IGW_QUICK_E_SCALE;
+    const double sv = s_hi + s_lo, cv = c_hi + c_lo;
+    const bool ok = (s_hi + (s_lo - es) == sv) && (s_hi + (s_lo + es) == sv) &&
+                    (c_hi + (c_lo - ec) == cv) && (c_hi + (c_lo + ec) == cv);
+    sincos_quadrant(kd, sv, cv, s_out, c_out);
+    return ok;
+}
+
+// sin and cos of x (radians), |x| < 2^20
+IGW_HD void igw_sincos(double x, double* s_out, double* c_out) {
+    if (x == 0.0) {
+        *s_out = x;  // keeps the sign of zero
+        *c_out = 1.0;
+        return;
+    }
+    if (!igw_sincos_quick(x, s_out, c_out)) igw_sincos_accurate(x, s_out, c_out);
+}
+
+// atan2(y, x) for finite arguments: the accurate evaluation (double-double throughout)
+IGW_HD double igw_atan2_accurate(double y, double x) {
     using namespace trigtab;
     const bool xneg = __builtin_signbit(x);
-    if (y == 0.0) return xneg ? __builtin_copysign(PI_HI, y) : __builtin_copysign(0.0, y);
-    if (x == 0.0) return __builtin_copysign(PIO2_HI, y);
     const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
     const bool swap = ay > ax;
     const double num = swap ? ax : ay, den = swap ? ay : ax;
@@ -149,10 +214,10 @@ IGW_HD double igw_atan2(double y, double x) {
     const double t1 = num / den;
     const double rem = __builtin_fma(-t1, den, num);  // exact remainder
     const dd_t t = dd_fast_two_sum(t1, rem / den);
-    const double jd = __builtin_rint(t.hi * 64.0);
+    const double jd = __builtin_rint(t.hi * 256.0);
     const int j = (int)jd;
-    const double tj = jd * 0.015625;
-    // u = (t - tj) / (1 + t tj), |u| <= 1/128
+    const double tj = jd * 0.00390625;
+    // u = (t - tj) / (1 + t tj), |u| <= 1/512
     const dd_t un = dd_two_sum(t.hi - tj, t.lo);
     const dd_t ud = dd_add_d(dd_mul_d(t, tj), 1.0);
     const dd_t u = (j == 0) ? t : dd_div(un, ud);
@@ -168,6 +233,72 @@ IGW_HD double igw_atan2(double y, double x) {
     if (swap) a = dd_add(dd_t{PIO2_HI, PIO2_LO}, dd_neg(a));
     if (xneg) a = dd_add(dd_t{PI_HI, PI_LO}, dd_neg(a));
     return __builtin_copysign(a.hi, y);
+}
+
+// The quick evaluation (see igw_sincos_quick): two divisions instead of five, the leading sums exact, the rest
+// in plain double, as hi + lo with an error bound E.  Error budget, absolute, |u| <= 2^-9: the quotients t and u
+// are formed as q1 + q2 with q1 = a * RN(1/b), q2 = (exact remainder) * RN(1/b): error <= 2^-104 relative; the
+// largest plain-double tail is u^3/3 <= 2^-28.6, computed to <= 5 * 2^-53 relative: 2^-79.3; four sums containing
+// it: <= 2^-81.6 each; dropped series term u^9/9 < 2^-84.  Total < 2^-78; E = 2^-75.  For j == 0 without a
+// reflection the result is ~t and may be tiny: every tail scales with t^3, the error is < 2^-71 t; E = 2^-68 t.
+IGW_HD bool igw_atan2_quick(double y, double x, double* out) {
+    using namespace trigtab;
+    const bool xneg = __builtin_signbit(x);
+    const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
+    const bool swap = ay > ax;
+    const double num = swap ? ax : ay, den = swap ? ay : ax;
+    const double rd = 1.0 / den;
+    const double t1 = num * rd;
+    const double t2 = __builtin_fma(-t1, den, num) * rd;  // the remainder is exact: t1 is within an ulp of num/den
+    const dd_t t = dd_fast_two_sum(t1, t2);
+    const double jd = __builtin_rint(t.hi * 256.0);
+    const int j = (int)jd;
+    const double tj = jd * 0.00390625;
+    double uh = t.hi, ul = t.lo;
+    if (j != 0) {
+        // u = un / ud:  un = (t - tj) (exact difference + t.lo), ud = 1 + t tj as a double-double
+        const dd_t un = dd_two_sum(t.hi - tj, t.lo);
+        const dd_t m = dd_two_prod(t.hi, tj);
+        dd_t ud = dd_fast_two_sum(1.0, m.hi);
+        ud.lo += m.lo + t.lo * tj;
+        const double ru = 1.0 / ud.hi;
+        const double u1 = un.hi * ru;
+        const double u2 = ((__builtin_fma(-u1, ud.hi, un.hi) + un.lo) - u1 * ud.lo) * ru;
+        const dd_t u = dd_fast_two_sum(u1, u2);
+        uh = u.hi; ul = u.lo;
+    }
+    // atan u = uh + ta:  ta = ul + uh^3 (-1/3 + w/5 - w^2/7), w = uh^2   (ul (1 - w) ~ ul: w ul < 2^-80)
+    const double w = uh * uh;
+    const double ta = ul + (w * uh) * (-0x1.5555555555555p-2 + w * (0x1.999999999999ap-3 + w * -0x1.2492492492492p-3));
+    const double Ah = ATAN[j][0], Al = ATAN[j][1];
+    dd_t a = dd_fast_two_sum(Ah, uh);  // Ah >= atan(1/256) > |u| for j >= 1; Ah == 0 for j == 0
+    a.lo += Al + ta;
+    if (swap) {  // pi/2 - a
+        const dd_t s = dd_two_sum(PIO2_HI, -a.hi);
+        a = dd_t{s.hi, s.lo + (PIO2_LO - a.lo)};
+    }
+    if (xneg) {  // pi - a
+        const dd_t s = dd_two_sum(PI_HI, -a.hi);
+        a = dd_t{s.hi, s.lo + (PI_LO - a.lo)};
+    }
+#ifndef IGW_QUICK_E_SCALE
+#define IGW_QUICK_E_SCALE 1.0
+#endif
+    const double e = ((j == 0 && !swap && !xneg) ? 0x1p-68 * uh : 0x1p-75) * IGW_QUICK_E_SCALE;
+    const double v = a.hi + a.lo;
+    *out = __builtin_copysign(v, y);
+    return (a.hi + (a.lo - e) == v) && (a.hi + (a.lo + e) == v);
+}
+
+// atan2(y, x) for finite arguments
+IGW_HD double igw_atan2(double y, double x) {
+    using namespace trigtab;
+    const bool xneg = __builtin_signbit(x);
+    if (y == 0.0) return xneg ? __builtin_copysign(PI_HI, y) : __builtin_copysign(0.0, y);
+    if (x == 0.0) return __builtin_copysign(PIO2_HI, y);
+    double a;
+    if (igw_atan2_quick(y, x, &a)) return a;
+    return igw_atan2_accurate(y, x);
 }
 
 }  // namespace igw

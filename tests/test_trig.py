@@ -67,6 +67,62 @@ def test_atan2_correctly_rounded():
     assert (np.abs(a - libm) <= np.spacing(np.abs(a))).all()
 
 
+def _variant(tmp_path, scale):
+    """The host trig library with the quick evaluations' error bound E scaled (tests only)."""
+    import ctypes
+    import subprocess
+    so = str(tmp_path / ('trig_e%g.so' % scale))
+    subprocess.check_call(['g++', '-O2', '-fPIC', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-shared',
+                           '-DIGW_QUICK_E_SCALE=(%r)' % float(scale), '-o', so, O._HERE + '/igw_trig_host.cpp', '-lm'])
+    return ctypes.CDLL(so)
+
+
+def test_quick_evaluations_never_accept_a_wrong_rounding(tmp_path):
+    """igw_sincos / igw_atan2 = a quick evaluation with an error bound E (Ziv's strategy) and the full
+    double-double one when hi + (lo +- E) straddles a rounding boundary.  Whenever the quick one accepts, its
+    result must be the accurate one's -- also with E shrunk 16 times (the margin of the bound) -- and it must
+    accept almost always (it is the fast path of the flying kernel)."""
+    import ctypes
+    rng = np.random.RandomState(7)
+    n = 400000
+    deg = np.concatenate([rng.uniform(-720, 720, n), rng.uniform(-90, 90, n),
+                          np.float32(rng.uniform(-5, 5, n // 4)).astype(np.float64), rng.uniform(-1e-3, 1e-3, n // 8),
+                          90 * rng.randint(-8, 9, n // 4) + rng.uniform(-1.5, 1.5, n // 4), rng.uniform(-1e-9, 1e-9, n // 8)])
+    x = np.ascontiguousarray(deg * (math.pi / 180.0))
+    x = np.ascontiguousarray(x[x != 0])
+    f32 = lambda a: np.float32(a).astype(np.float64)  # noqa: E731
+    ya = np.concatenate([f32(rng.uniform(-1, 1, n)), rng.uniform(-1, 1, n), rng.uniform(-1e-3, 1e-3, n // 4), rng.uniform(-1e-9, 1e-9, n // 8)])
+    xa = np.concatenate([f32(rng.uniform(-1, 1, n)), rng.uniform(-1, 1, n), rng.uniform(-1, 1, n // 4), rng.uniform(-1, 1, n // 8)])
+    keep = (ya != 0) & (xa != 0)
+    ya, xa = np.ascontiguousarray(ya[keep]), np.ascontiguousarray(xa[keep])
+    for scale, min_accept in ((1.0, 0.9999), (1.0 / 16, 0.99999)):
+        T = _variant(tmp_path, scale)
+        vp, lg = ctypes.c_void_p, ctypes.c_long
+        T.igw_host_sincos_quick_array.argtypes = [vp, vp, vp, vp, lg]
+        T.igw_host_sincos_accurate_array.argtypes = [vp, vp, vp, lg]
+        T.igw_host_atan2_quick_array.argtypes = [vp, vp, vp, vp, lg]
+        T.igw_host_atan2_accurate_array.argtypes = [vp, vp, vp, lg]
+        s, c, sa, ca = (np.zeros_like(x) for _ in range(4))
+        ok = np.zeros(len(x), np.uint8)
+        T.igw_host_sincos_quick_array(x.ctypes.data, s.ctypes.data, c.ctypes.data, ok.ctypes.data, len(x))
+        T.igw_host_sincos_accurate_array(x.ctypes.data, sa.ctypes.data, ca.ctypes.data, len(x))
+        acc = ok.astype(bool)
+        assert not (acc & ((s != sa) | (c != ca))).any(), f'sincos: wrong acceptance at E x {scale}'
+        assert acc.mean() >= min_accept, (scale, acc.mean())
+        q, qa = np.zeros_like(xa), np.zeros_like(xa)
+        ok = np.zeros(len(xa), np.uint8)
+        T.igw_host_atan2_quick_array(ya.ctypes.data, xa.ctypes.data, q.ctypes.data, ok.ctypes.data, len(xa))
+        T.igw_host_atan2_accurate_array(ya.ctypes.data, xa.ctypes.data, qa.ctypes.data, len(xa))
+        acc = ok.astype(bool)
+        assert not (acc & ((q != qa) | (np.signbit(q) != np.signbit(qa)))).any(), f'atan2: wrong acceptance at E x {scale}'
+        assert acc.mean() >= min_accept, (scale, acc.mean())
+    # and the accurate evaluations alone are correctly rounded (the public functions are tested above)
+    idx = rng.choice(len(x), 4000, replace=False)
+    assert all(sa[i] == _cr(mpmath.sin, x[i]) and ca[i] == _cr(mpmath.cos, x[i]) for i in idx)
+    idx = rng.choice(len(xa), 4000, replace=False)
+    assert all(qa[i] == _cr(mpmath.atan2, ya[i], xa[i]) for i in idx)
+
+
 def test_special_values():
     T = O.trig_host()
     assert T.igw_host_sin(0.0) == 0.0 and math.copysign(1, T.igw_host_sin(-0.0)) == -1 and T.igw_host_cos(-0.0) == 1.0

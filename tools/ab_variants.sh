@@ -13,7 +13,7 @@ done
 for rep in 1 2 3; do
   i=0
   for FL in "$@"; do
-    IGW_LIB=$PWD/gridworld_amd/libigw_ab$i.so python3 bench.py --no-cpu-baseline --no-fused --steps 400 --warmup 20 2>/dev/null | python3 -c "
+    IGW_LIB=$PWD/gridworld_amd/libigw_ab$i.so python3 bench.py --no-cpu-baseline --no-fused --no-async --mode ${MODE:-walking} --steps 400 --warmup 20 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('rep $rep variant $i [$FL] kernel %.3f us  %.3f G' % (d['roofline']['kernel_avg_ms']*1e3, d['value']/1e9))"
     i=$((i+1))
