@@ -17,6 +17,19 @@ WORKER = textwrap.dedent('''
     assert world == 2
     total = 65536 * world + 3
     lo, hi = gd.shard_envs(total, rank, world)
+    nb = gd.NodeBarrier()
+    for i in range(200):            # the shared-memory barrier bench.py brackets its window with
+        if i == 100 and rank == 1:
+            time.sleep(0.2)         # a late rank holds the other one back
+            late = time.perf_counter()
+        nb.wait()
+        if i == 100 and rank == 0:
+            released = time.perf_counter()
+    t0 = time.perf_counter()
+    for i in range(1000):
+        nb.wait()
+    nb_us = (time.perf_counter() - t0) / 1000 * 1e6
+    stamps = gd.gather_counts(int((released if rank == 0 else late) * 1e6))  # CLOCK_MONOTONIC: one clock for both
     gd.barrier()
     t = time.perf_counter()
     steps = (hi - lo) * 10          # 10 "steps" of this rank's shard
@@ -26,7 +39,8 @@ WORKER = textwrap.dedent('''
     tot, mx = gd.reduce_window(steps, el)
     counts = gd.gather_counts(steps)
     if rank == 0:
-        print(json.dumps(dict(total=tot, max_elapsed=mx, counts=counts, lo=lo, hi=hi, expect=total * 10)))
+        print(json.dumps(dict(total=tot, max_elapsed=mx, counts=counts, lo=lo, hi=hi, expect=total * 10, nb_us=nb_us,
+                              released_after_late_rank=stamps[0] >= stamps[1])))
 ''') % ROOT
 
 
@@ -55,6 +69,8 @@ def test_gloo_world2_sharding_and_reduction(tmp_path):
     assert d['total'] == d['expect'] == sum(d['counts'])
     assert d['max_elapsed'] >= 0.1
     assert d['lo'] == 0 and d['hi'] == (65536 * 2 + 3) // 2
+    assert d['released_after_late_rank'], d
+    assert d['nb_us'] < 2000, d  # the node barrier is a spin on shared memory (microseconds on idle cores)
 
 
 def test_shard_envs_partition():
