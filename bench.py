@@ -14,7 +14,8 @@ maximal_intersection reward), uniform random actions that are already resident i
 region starts.  Weak scaling: every rank owns its own 65,536 envs; no data-path collective.
 
 Steady state before the clock: episodes are de-synchronised (every env starts at a random step of its
-episode, then an untimed pre-roll of at least 250 steps and 0.3 s), so any timed window -- also a 20-step
+episode, then an untimed pre-roll of at least 250 steps; 0.3 s more of it right before the clock, after the
+graph capture, so the GPU is at its working clocks), so any timed window -- also a 20-step
 one -- sees the steady-state fraction of grid-changing steps and about N/250 auto-resets per launch.  The K
 timed launches are 2 eager launches followed by ONE HIP-graph replay of the other K - 2 (captured and
 instantiated before the clock), inside the barrier / synchronize bracket, so a short window is
@@ -243,17 +244,17 @@ def main():
         def fly_step(a, t):
             L.check(env.lib.igw_step_flying(env.ctx, a[0][t].data_ptr(), a[1][t].data_ptr(), a[2][t].data_ptr(),
                                             a[3][t].data_ptr(), env._stream()), 'igw_step_flying')
-        if not args.lockstep:
-            # untimed pre-roll to the steady state: at least one episode length, and at least 0.3 s of work so a GPU
-            # that has been idle (fresh process, task upload) is at its working clocks -- always FRESH random actions
+        def busy(seconds, min_steps):
+            """Untimed stepping with FRESH random actions: the pre-roll to the steady state / the clock ramp."""
             t_ramp, n_pre = time.perf_counter(), 0
-            while n_pre < MAX_STEPS or time.perf_counter() - t_ramp < 0.3:
+            while n_pre < min_steps or time.perf_counter() - t_ramp < seconds:
                 pre = fly_actions(50)
                 for t in range(50):
                     fly_step(pre, t)
                 torch.cuda.synchronize(device)
                 n_pre += 50
-            del pre
+        if not args.lockstep:
+            busy(0.0, MAX_STEPS)  # at least one episode length
         acts = fly_actions(W + K)
         # the timed loop passes pre-computed device pointers: slicing a tensor per step costs more host time
         # than the launch itself
@@ -266,15 +267,19 @@ def main():
             if rc:
                 L.check(rc, 'igw_step_flying')
     else:
-        if not args.lockstep:
-            # untimed pre-roll to the steady state (fused rollout, in-kernel random actions): at least one episode
-            # length, and at least 0.3 s of work so a GPU that has been idle (fresh process, task upload) is at its
-            # working clocks -- without it a 20-step window measures the clock ramp, not the kernel
+        pre_rolled = [0]
+
+        def busy(seconds, min_steps):
+            """Untimed stepping with fresh in-kernel random actions (fused rollout): the pre-roll to the steady
+            state / the clock ramp."""
             t_ramp, n_pre = time.perf_counter(), 0
-            while n_pre < MAX_STEPS or time.perf_counter() - t_ramp < 0.3:
-                env.rollout(MAX_STEPS, seed=args.seed + 17 + n_pre, t0=n_pre, env_offset=env_offset)
+            while n_pre < min_steps or time.perf_counter() - t_ramp < seconds:
+                env.rollout(MAX_STEPS, seed=args.seed + 17 + pre_rolled[0], t0=pre_rolled[0], env_offset=env_offset)
                 torch.cuda.synchronize(device)
                 n_pre += MAX_STEPS
+                pre_rolled[0] += MAX_STEPS
+        if not args.lockstep:
+            busy(0.0, MAX_STEPS)  # at least one episode length
         chunk = 256
         actions = [env.fill_actions(min(chunk, W + K - t0), seed=args.seed, t0=t0, env_offset=env_offset)
                    for t0 in range(0, W + K, chunk)]
@@ -351,6 +356,11 @@ def main():
     # than later ones, which is 10-20 % of a 20-step window and nothing to do with the step kernel.  A rehearsal
     # steps the envs like any other warm-up step; the measured pass is always the LAST one, a complete window of
     # its own, and the rehearsals' ms/step are reported next to it (config.rehearsal_ms_per_step).
+    # ... and, right before them, 0.3 s of untimed stepping: task upload, graph capture and instantiation leave the
+    # GPU idle for tens of milliseconds and its clocks drop; a 20-step window (0.3 ms) would otherwise be measured
+    # on the ramp (16.3 us per launch instead of 15.3)
+    if not args.lockstep:
+        busy(0.3, 0)
     rehearsal_ms = [round(1e3 * window()[0] / K, 5) for _ in range(args.rehearsals)]
     elapsed, st0_dev, host_tl = window()
     if os.environ.get('IGW_BENCH_TRACE'):
@@ -436,7 +446,7 @@ def main():
                    'launches_per_step': 1,
                    'timed_as': 'eager launches' if graph is None else f'{head} eager launches + one HIP-graph replay of the other {K - head}',
                    'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + pre-roll)',
-                   'setup': 'untimed: task upload, pre-roll of >= 250 steps and >= 0.3 s with fresh random actions (steady state, clock ramp), graph capture + one replay, %d untimed rehearsals of the W + K sequence (host code paths warm), then the W warm-up steps and the clock' % args.rehearsals,
+                   'setup': 'untimed: task upload, pre-roll of >= 250 steps with fresh random actions (steady state), graph capture + one replay, 0.3 s more of such stepping (clock ramp), %d untimed rehearsals of the W + K sequence (host code paths warm), then the W warm-up steps and the clock' % args.rehearsals,
                    'rehearsal_ms_per_step': rehearsal_ms,
                    'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused,

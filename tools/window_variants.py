@@ -50,6 +50,7 @@ def make_graph(lo, hi):
 
 
 g18, g19, g20 = make_graph(W + 2, W + K), make_graph(W + 1, W + K), make_graph(W, W + K)
+g17, g16, g14 = make_graph(W + 3, W + K), make_graph(W + 4, W + K), make_graph(W + 6, W + K)
 
 
 def window(head, graph, ev_inside, ev_timing=True, stamps=None):
@@ -87,6 +88,9 @@ variants = [
     ('C  ev0 before, 1 eager + graph19', dict(head=1, graph=g19, ev_inside=False)),
     ('D  ev0 before, graph20', dict(head=0, graph=g20, ev_inside=False)),
     ('E  ev0 before, 20 eager', dict(head=K, graph=None, ev_inside=False)),
+    ('H  ev0 before, 3 eager + graph17', dict(head=3, graph=g17, ev_inside=False)),
+    ('I  ev0 before, 4 eager + graph16', dict(head=4, graph=g16, ev_inside=False)),
+    ('J  ev0 before, 6 eager + graph14', dict(head=6, graph=g14, ev_inside=False)),
     ('F  untimed events, 2 eager + graph18', dict(head=2, graph=g18, ev_inside=False, ev_timing=False)),
     ('G  untimed events, 20 eager', dict(head=K, graph=None, ev_inside=False, ev_timing=False)),
 ]
