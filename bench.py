@@ -174,11 +174,8 @@ def load_profile(suffix):
 
 
 def auto_lanes(n):
-    """The library's automatic group width (include/igw.h: IGW_TARGET_WAVES)."""
-    lanes = 64
-    while lanes > 4 and n * lanes // 64 > 1024:
-        lanes //= 2
-    return lanes
+    """The library's automatic group width (include/igw.h: IGW_AUTO_*_MAX)."""
+    return 32 if n <= 1024 else 16 if n <= 4096 else 8 if n <= 24576 else 4
 
 
 def dry_run(args):

@@ -1438,12 +1438,11 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
         return fail(IGW_ERR_INVALID, "igw_create: unknown action_space");
     int gs = cfg->lanes_per_env;
     if (gs == 0) {
-        // auto: four lanes per env (coordinate-split ray march, axis-split collide) measured fastest at every batch
-        // from 16,384 envs up to 1,048,576 (2.2.. 5.6 G env-steps/s); smaller batches take wider groups so that a
-        // launch still has about IGW_TARGET_WAVES wavefronts (one per SIMD) to spread over the chip:
-        // 4,096 envs -> 16 lanes, 1,024 -> 64.
-        gs = 64;
-        while (gs > 4 && (long long)cfg->num_envs * gs / 64 > IGW_TARGET_WAVES) gs >>= 1;
+        // auto: the width measured fastest for the batch size (include/igw.h).  Four lanes per env (coordinate-split
+        // ray march, axis-split collide) win from 32,768 envs up to 1,048,576; smaller batches need wider groups to
+        // put enough wavefronts on the chip.
+        gs = cfg->num_envs <= IGW_AUTO_32_MAX ? 32 : cfg->num_envs <= IGW_AUTO_16_MAX ? 16
+           : cfg->num_envs <= IGW_AUTO_8_MAX ? 8 : 4;
     }
 #ifndef IGW_DIAG
     if (cfg->reserved != 0)

@@ -35,11 +35,13 @@ extern "C" {
 #endif
 
 #define IGW_VERSION 2
-/* igw_config.lanes_per_env == 0 picks the group width: 4 lanes per env from 16,384 envs up (measured fastest at
- * every larger batch), wider power-of-two groups (8, 16, ... 64 = one wavefront per env) for smaller batches so
- * that a launch keeps about this many wavefronts (one per SIMD of an MI355X).  1 and 2 lanes per env exist and
- * are tested, but are never chosen automatically. */
-#define IGW_TARGET_WAVES 1024
+/* igw_config.lanes_per_env == 0 picks the group width measured fastest on an MI355X for the batch size
+ * (profiles/r02_sweep_lanes*.txt): 32 lanes per env up to IGW_AUTO_32_MAX envs, 16 up to IGW_AUTO_16_MAX, 8 up to
+ * IGW_AUTO_8_MAX, 4 beyond (a launch then has between about 512 and 4,096 wavefronts for 1,024 SIMDs).  64 (one
+ * wavefront per env), 2 and 1 lanes per env exist and are tested, but are never chosen automatically. */
+#define IGW_AUTO_32_MAX 1024
+#define IGW_AUTO_16_MAX 4096
+#define IGW_AUTO_8_MAX 24576
 
 /* dense voxel grid [y+1][x+5][z+5], int8 (env.py:34, 136-142) */
 #define IGW_GRID_Y 9
@@ -98,7 +100,7 @@ typedef struct igw_config {
     int32_t autoreset;         /* 0: caller resets on done (reference loop); 1: reset inside step */
     double right_placement_scale; /* env.py:335 */
     double wrong_placement_scale; /* env.py:337 */
-    int32_t lanes_per_env;     /* 0 = automatic from num_envs (see IGW_TARGET_WAVES); or 64, 32, ..., 1 */
+    int32_t lanes_per_env;     /* 0 = automatic from num_envs (see IGW_AUTO_*_MAX); or 64, 32, ..., 1 */
     int32_t reserved;          /* must be 0 (ablation switches of the IGW_DIAG build) */
     int64_t env_index_base;    /* global index of env 0 of this context (rank offset, sub-batch offset): keys the
                                 * on-device task samplers so shards and sub-batches draw different streams */

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box, one call = one box: throughput of 1 / 2 sub-batches (tools/async_split.py) with different issue-priority
-# maps for overlapping launches (igw_set_overlap_hint).   usage: tools/async_ab.sh "" "-DIGW_PRIO_MAP_OVERLAP=0x00112233" ...
+# maps (compile-time).   usage: tools/async_ab.sh "" "-DIGW_PRIO_MAP=0x33221100" "-DIGW_PRIO_MAP=0" ...
 set -u
 i=0
 for FL in "$@"; do
