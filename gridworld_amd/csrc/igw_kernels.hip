@@ -710,6 +710,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
     int hmax_l = 0;
     uint64_t m = mask;
     for (int base = 0; base < E; base += R) {
+        if (base > 0 && IGW_DIAG_FLAG(p, 256)) break;  // diag 256: what the second pass of a wave with more than R changes costs
         const int cnt = min(R, E - base);
         int ll[R], r_env[R], r_task[R], r_cell[R], r_new[R], r_old[R];
 #pragma unroll
