@@ -372,7 +372,7 @@ def main():
     n_ranks = len(gdist.gather_counts(rank, device))
 
     # secondary: fused T-step rollout (state resident in LDS/registers, in-kernel RNG)
-    fused = None
+    fused = fused_rec = None
     if not args.no_fused:
         Tf = 250
         env.rollout(Tf, seed=args.seed + 1, t0=0, env_offset=env_offset)  # warm
@@ -384,6 +384,17 @@ def main():
         gdist.barrier(device)
         f_steps, f_el = gdist.reduce_window(N * Tf, time.perf_counter() - t0, device)
         fused = f_steps / f_el
+        # the same fused loop over RECORDED actions (igw_rollout_walking_actions): the first chunk of the timed actions
+        Tr = actions[0].shape[0]
+        env.rollout_actions(actions[0])  # warm
+        torch.cuda.synchronize(device)
+        gdist.barrier(device)
+        t0 = time.perf_counter()
+        env.rollout_actions(actions[0])
+        torch.cuda.synchronize(device)
+        gdist.barrier(device)
+        r_steps, r_el = gdist.reduce_window(N * Tr, time.perf_counter() - t0, device)
+        fused_rec = r_steps / r_el
 
     # secondary: the same kernel as two independent sub-batches on two HIP streams (VecGridWorld.split, the
     # EnvPool-style asynchronous mode): no barrier between the halves, so the start of one half's next step
@@ -447,6 +458,7 @@ def main():
                    'rehearsal_ms_per_step': rehearsal_ms,
                    'resets_in_window': resets, 'p_changed': p,
                    'fused_rollout_env_steps_per_s': fused,
+                   'fused_rollout_recorded_actions_env_steps_per_s': fused_rec,
                    'async_2_subbatches_env_steps_per_s': async2},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': hbm_bytes,

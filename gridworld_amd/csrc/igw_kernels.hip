@@ -1067,10 +1067,17 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     stamp(p, 6);
 }
 
-// T fused walking steps, state resident in registers + LDS, counter-RNG actions, auto-reset on done
+// T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
+// `actions` [T][N] -- the caller's, with optional per-step rewards / dones [T][N] out and the context's autoreset
+// setting (igw_rollout_walking_actions).
+struct RolloutIO {
+    const int32_t* actions;
+    float* rewards;
+    uint8_t* dones;
+};
 template <int GS>
 __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, unsigned long long seed,
-                                                        long long t0, long long env_offset) {
+                                                        long long t0, long long env_offset, RolloutIO io) {
     __shared__ BlockShared<GS> sh;
     const Grp<GS> G;
     TrigCtx trig;
@@ -1113,7 +1120,9 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
         bool need = false;
         if (active) {
             e.step_no = min(e.step_no + 1, 65535);
-            const WalkAct w = parse_walking_discrete(rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t)));
+            const int action = io.actions ? io.actions[(size_t)t * p.n_envs + env]
+                                          : rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
+            const WalkAct w = parse_walking_discrete(action);
             ch = world_act<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
                                           w.remove, w.add, mv);
             if (ch.idx >= 0 && has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
@@ -1143,8 +1152,12 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
             o = finish_step(p, e, env_max_int, size_new, mi);
             n_changed += need;
             n_updates += changed;
-            do_reset = o.done;
+            do_reset = o.done && (io.actions == nullptr || p.autoreset);
             last_reset = do_reset;
+            if (G.gl == 0) {
+                if (io.rewards) io.rewards[(size_t)t * p.n_envs + env] = (float)o.reward;
+                if (io.dones) io.dones[(size_t)t * p.n_envs + env] = o.done ? 1 : 0;
+            }
             // colours go to HBM right away (a later break of this launch reads them)
             if (ch.idx >= 0 && !do_reset && G.gl == 0) grid_g[ch.idx] = (int8_t)ch.new_val;
         }
@@ -1681,7 +1694,20 @@ int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int6
     if (T == 0) return IGW_OK;
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(rollout_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, (long long)T, (unsigned long long)seed,
-                                            (long long)t0, (long long)env_offset));
+                                            (long long)t0, (long long)env_offset, RolloutIO{nullptr, nullptr, nullptr}));
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_rollout_walking_actions(igw_ctx* ctx, const int32_t* actions, int64_t T, float* rewards, uint8_t* dones,
+                                void* stream) {
+    CHECK_CTX("igw_rollout_walking_actions");
+    if (ctx->cfg.action_space != IGW_WALKING_DISCRETE) return fail(IGW_ERR_INVALID, "igw_rollout_walking_actions: context was created for another action space");
+    if (T < 0 || (T > 0 && !actions)) return fail(IGW_ERR_INVALID, "igw_rollout_walking_actions: bad argument");
+    if (T == 0) return IGW_OK;
+    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(rollout_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
+                                            (hipStream_t)stream, ctx->kp, (long long)T, 0ull, 0ll, 0ll,
+                                            RolloutIO{actions, rewards, dones}));
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }

@@ -281,6 +281,26 @@ class VecGridWorld:
         L.check(self.lib.igw_rollout_walking(self.ctx, int(T), int(seed), int(t0), int(env_offset),
                                              self._stream()), 'igw_rollout_walking')
 
+    def rollout_actions(self, actions, return_rewards=False):
+        """Fused replay of a recorded action sequence: `actions` int32 [T, N] (Discrete(18) ids) -- bit-identical to
+        T calls of step(), in one launch without a barrier between the steps of different envs (the context's
+        autoreset setting applies).  With return_rewards: (rewards float32 [T, N], dones uint8 [T, N])."""
+        self._need_tasks()
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dim() != 2 or a.shape[1] != self.num_envs:
+            raise ValueError(f'actions must be [T, {self.num_envs}], got {tuple(a.shape)}')
+        a = a.to(torch.int32).contiguous()
+        T = a.shape[0]
+        rw = dn = None
+        if return_rewards:
+            rw = torch.empty((T, self.num_envs), dtype=torch.float32, device=self.device)
+            dn = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+        L.check(self.lib.igw_rollout_walking_actions(self.ctx, a.data_ptr(), int(T), rw.data_ptr() if rw is not None else None,
+                                                     dn.data_ptr() if dn is not None else None, self._stream()),
+                'igw_rollout_walking_actions')
+        self._keep = a  # the launch reads it asynchronously
+        return (rw, dn) if return_rewards else None
+
     def fill_actions(self, n_steps, seed, t0=0, env_offset=0):
         a = torch.empty((n_steps, self.num_envs), dtype=torch.int32, device=self.device)
         L.check(self.lib.igw_fill_actions_walking(self.ctx, a.data_ptr(), int(n_steps), int(t0), int(seed),

@@ -15,7 +15,7 @@
  *   igw_step_walking_dict <- same with parse_walking_action, discretize=False (core/world.py:396-414)
  *   igw_task_eval      <- Task.maximal_intersection / argmax_intersection
  *                         (tasks/task.py:121-161)
- *   igw_rollout_walking<- the loop of examples/run_env.py:18-26 fused on device
+ *   igw_rollout_walking, igw_rollout_walking_actions <- the loop of examples/run_env.py:18-26 fused on device
  *
  * Plain pointers and sizes only; every data pointer is a DEVICE pointer owned by
  * the caller (e.g. torch tensors) and must outlive the context.  All calls are
@@ -227,6 +227,13 @@ int igw_step_walking_dict(igw_ctx* ctx, const uint8_t* buttons, const float* cam
  * (seed, env_offset + env, t) for t = t0 .. t0+T-1; auto-reset on done regardless of cfg.autoreset. */
 int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int64_t env_offset,
                         void* stream);
+/* The same fused loop over caller-supplied actions: T steps per env with actions[t][env] (int32 [T][N], 0..17) --
+ * exactly T calls of igw_step_walking (the context's autoreset setting applies), in one launch and without a
+ * barrier between the steps of different envs.  rewards (float [T][N]) / dones (uint8 [T][N]) receive every step's
+ * values when not NULL; the per-env outputs of igw_buffers hold the last step's, as after igw_step_walking.
+ * <- the loop of examples/run_env.py:18-26 over a recorded action sequence.  Not with the episode log. */
+int igw_rollout_walking_actions(igw_ctx* ctx, const int32_t* actions, int64_t T, float* rewards, uint8_t* dones,
+                                void* stream);
 /* fills actions[n_steps][N] with the same counter RNG (t = t0 .. t0+n_steps-1) */
 int igw_fill_actions_walking(igw_ctx* ctx, int32_t* actions, int64_t n_steps, int64_t t0, uint64_t seed,
                              int64_t env_offset, void* stream);

@@ -331,6 +331,41 @@ def test_every_env_of_a_wave_changes_in_the_same_step(gs):
     _check_occ(env)
 
 
+@pytest.mark.parametrize('autoreset', [True, False])
+@pytest.mark.parametrize('gs', [0, 4, 1])
+def test_rollout_over_recorded_actions_equals_stepping(gs, autoreset):
+    """igw_rollout_walking_actions: T fused steps over the caller's actions == T calls of step(), every step's reward
+    and done included, with and without auto-reset (without it the envs keep stepping past done, as the
+    reference does)."""
+    from gridworld_amd import VecGridWorld
+    n, T = 600, 330
+    tg = _rt20_targets(n, 31)
+    kw = dict(size_reward=False, max_steps=120, autoreset=autoreset, lanes_per_env=gs)
+    rng = np.random.RandomState(5)
+    acts = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12, 13, 14, 14, 15, 16, 16, 17, 17, 17, 0], size=(T, n)).astype(np.int32)
+    a = VecGridWorld(n, **kw)
+    a.set_tasks(tg)
+    a.reset()
+    b = VecGridWorld(n, **kw)
+    b.set_tasks(tg)
+    b.reset()
+    acts_d = torch.as_tensor(acts, device=a.device)
+    rw, dn = a.rollout_actions(acts_d, return_rewards=True)
+    rw_b, dn_b = [], []
+    for t in range(T):
+        b.step(acts_d[t])
+        rw_b.append(b.reward.clone())
+        dn_b.append(b.done.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(rw.view(torch.int32), torch.stack(rw_b).view(torch.int32))
+    assert torch.equal(dn, torch.stack(dn_b))
+    for name in ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'agent_pos', 'inventory', 'compass', 'reward', 'done'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    sa, sb = a.stats(), b.stats()
+    assert sa['changed'] == sb['changed'] and sa['resets'] == sb['resets'] and sa['rescans'] == sb['rescans']
+    assert (sa['resets'] > 0) == autoreset
+
+
 def test_product_does_not_import_oracle():
     import sys
     import gridworld_amd  # noqa: F401
