@@ -159,11 +159,13 @@ def cpu_baseline(seed):
             'p_changed': changed / max(steps, 1)}
 
 
-def load_profile(suffix):
-    """Latest committed profile summary profiles/*<suffix> (json), or None."""
+def load_profile(suffix, flying=False):
+    """Latest committed profile summary profiles/r*_<suffix> (walking) or r*_flying_<suffix> (json), or None."""
     import glob
     best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix))):
+    for p in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_' + ('flying_' if flying else '') + suffix))):
+        if ('flying' in os.path.basename(p)) != flying:
+            continue
         try:
             with open(p) as f:
                 best = json.load(f)
@@ -428,8 +430,8 @@ def main():
     resets = st1['resets'] - st0['resets']
     bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4
     achieved = N * bytes_per_step / (kernel_ms * 1e-3) / 1e9
-    traffic = None if flying else load_profile('traffic.json')
-    issue = None if flying else load_profile('issue.json')
+    traffic = load_profile('traffic.json', flying)
+    issue = load_profile('issue.json', flying)
     hbm_bytes = None if traffic is None else traffic.get('hbm_bytes_per_launch')
     out = {
         'metric': 'env-steps/sec (render=False, vector_state) at N parallel envs, 1/2/4/8 GPU',
