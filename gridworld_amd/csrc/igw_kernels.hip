@@ -807,9 +807,11 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 const uint4 now = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
                 if (now.x != before[k].x || now.y != before[k].y || now.z != before[k].z || now.w != before[k].w)
                     reinterpret_cast<uint4*>(p.hist + (size_t)r_env[k] * HIST_ROW)[lane] = now;
-                const uint32_t m01 = max(max(now.x & 0xffff, now.x >> 16), max(now.y & 0xffff, now.y >> 16));
-                const uint32_t m23 = max(max(now.z & 0xffff, now.z >> 16), max(now.w & 0xffff, now.w >> 16));
-                const int best = wave_max_nonneg((int)max(m01, m23));
+                // the eight 16-bit counts of the lane: three packed maxima (v_pk_max_u16), then the two halves
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const us2 pm = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(us2, now.x), __builtin_bit_cast(us2, now.y)),
+                                                         __builtin_elementwise_max(__builtin_bit_cast(us2, now.z), __builtin_bit_cast(us2, now.w)));
+                const int best = wave_max_nonneg((int)max((uint32_t)pm.x, (uint32_t)pm.y));
                 if (lane / GS == ll[k] / GS) hmax_l = best;
             }
         }
