@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 for mode in graph nograph; do
     extra=""; [ $mode = nograph ] && extra="--no-graph"
-    rocprofv3 --kernel-trace --output-format csv -d $OUT/$mode -- python3 bench.py --steps $K --warmup 5 --no-cpu-baseline --no-fused $extra > $OUT/$mode.json 2> $OUT/$mode.log
+    rocprofv3 --kernel-trace --output-format csv -d $OUT/$mode -- python3 bench.py --steps $K --warmup 5 --no-cpu-baseline --no-fused --no-async $extra > $OUT/$mode.json 2> $OUT/$mode.log
     python3 - $OUT/$mode $K <<'PY'
 import csv, glob, sys
 d, K = sys.argv[1], int(sys.argv[2])
