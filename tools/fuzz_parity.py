@@ -66,7 +66,21 @@ def main():
         ob.reset()
         try:
             O.use_device_trig(mode == 'flying')
-            for t in range(T):
+            fused = mode == 'walking' and c % 3 == 0   # every third walking case: chunks through the fused replay
+            t = 0
+            while fused and t < T:
+                w = np.array([1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 3, 4, 4], float)
+                chunk = rng.choice(18, size=(int(rng.choice([1, 7, 30])), n), p=w / w.sum()).astype(np.int32)
+                rw, dn = env.rollout_actions(torch.as_tensor(chunk), return_rewards=True)
+                torch.cuda.synchronize()
+                rw, dn = rw.cpu().numpy(), dn.cpu().numpy()
+                for k in range(len(chunk)):
+                    ob.step_walking(chunk[k], autoreset=autoreset, nthreads=8)
+                    if not (np.array_equal(rw[k].view(np.uint32), ob.reward.view(np.uint32)) and np.array_equal(dn[k], ob.done)):
+                        raise AssertionError(f'{desc} fused chunk at step {t + k}: per-step reward / done differ')
+                t += len(chunk)
+                compare(env, ob, f'{desc} after fused chunk ending at step {t}')
+            for t in range(0 if not fused else T, T):
                 if mode == 'walking':
                     w = np.array([1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 3, 4, 4], float)
                     a = rng.choice(18, size=n, p=w / w.sum()).astype(np.int32)
@@ -83,7 +97,7 @@ def main():
                 compare(env, ob, f'{desc} step {t}')
         finally:
             O.use_device_trig(False)
-        print('ok', desc, flush=True)
+        print('ok', desc + (' [fused replay]' if mode == 'walking' and c % 3 == 0 else ''), flush=True)
     print('fuzz: all', cases, 'cases bit-exact')
 
 
