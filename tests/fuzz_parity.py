@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""GPU box: randomised parity fuzz -- random batch sizes (ragged), lanes per env, reward mode, max_steps, start
+"""GPU box: randomised parity fuzz (test infrastructure: it drives the CPU oracle, so it lives under tests/) -- random batch sizes (ragged), lanes per env, reward mode, max_steps, start
 grids, scales and action mixes, HIP path vs the CPU oracle at every step (walking and, with the oracle in
 device-trig mode, flying).  Not part of the test suite (minutes); prints the first mismatch.
 
-    python tools/fuzz_parity.py [n_cases] [seed]"""
+    python tests/fuzz_parity.py [n_cases] [seed]"""
 import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from gridworld_amd import VecGridWorld  # noqa: E402
