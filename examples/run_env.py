@@ -5,6 +5,7 @@
     python examples/run_env.py --vec 65536     # N envs, tensor observations (the fast path)
     python examples/run_env.py --vec 65536 --random-tasks      # RandomTasks.sample_task on the device at every reset
     python examples/run_env.py --vec 4096 --log 2 episodes/    # dump the episodes of the first 2 envs (Logged-style npz)
+    python examples/run_env.py --vec 65536 --replay            # the same loop over a recorded action sequence, fused into one launch
 """
 import argparse
 import os
@@ -35,7 +36,7 @@ def single(episodes):
     print(f'steps per second: {steps / time:.4f}')
 
 
-def vec(n, steps, random_tasks=False, log=None):
+def vec(n, steps, random_tasks=False, log=None, replay=False):
     env = G.make_vec(n, size_reward=False, autoreset=True)
     if random_tasks:   # RandomTasks(max_blocks=20, max_dist=2, num_colors=6), sampled on the device at every reset
         env.set_random_tasks(True, seed=0, max_blocks=20, height_levels=1, max_dist=2, num_colors=6)
@@ -49,8 +50,11 @@ def vec(n, steps, random_tasks=False, log=None):
     actions = torch.randint(0, 18, (steps, n), dtype=torch.int32, device=env.device)
     torch.cuda.synchronize()
     t = perf_counter()
-    for k in range(steps):
-        obs, reward, done, info = env.step(actions[k])   # tensors in HBM; a policy would read obs here
+    if replay:   # open-loop: all steps in one launch, every step's reward / done returned
+        rewards, dones = env.rollout_actions(actions, return_rewards=True)
+    else:
+        for k in range(steps):
+            obs, reward, done, info = env.step(actions[k])   # tensors in HBM; a policy would read obs here
     torch.cuda.synchronize()
     dt = perf_counter() - t
     print(f'{n} envs x {steps} steps: {n * steps / dt / 1e6:.1f} M env-steps per second; counters {env.stats()}')
@@ -66,5 +70,6 @@ if __name__ == '__main__':
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--random-tasks', action='store_true')
     ap.add_argument('--log', nargs=2, metavar=('N_ENVS', 'DIR'))
+    ap.add_argument('--replay', action='store_true')
     a = ap.parse_args()
-    vec(a.vec, a.steps, a.random_tasks, a.log) if a.vec else single(a.episodes)
+    vec(a.vec, a.steps, a.random_tasks, a.log, a.replay) if a.vec else single(a.episodes)
