@@ -519,15 +519,74 @@ __device__ inline void key_unpack(int key, int& x, int& y, int& z) {
 
 // Sample k is position + k sequential additions of vector/5 (the reference's recurrence, so the
 // rounding of every partial sum is reproduced).
+// `scratch`: WAVE * 10 words of LDS owned by the wave (groups of four lanes only; see there).
 template <int GS, bool PRIO = false>
 __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x, double y, double z,
-                               double vx, double vy, double vz, bool boost = false) {
+                               double vx, double vy, double vz, bool boost = false, uint32_t* scratch = nullptr) {
     constexpr int SAMPLES = 40;  // max_distance 8 * m 5
-    const double sx = div5(vx), sy = div5(vy), sz = div5(vz);  // dx / m with m = 5
     Hit h;
     h.hit = false; h.have_prev = false;
     h.bx = h.by = h.bz = 0;
     h.px = h.py = h.pz = 0;
+    if constexpr (GS == 4) {
+        // Coordinate split: lane 0 / 1 / 2 of the group carries the x / y / z recurrence alone (39 sequential
+        // adds instead of 117 per lane; one division by 5 instead of three) and rounds + clamps its coordinate of
+        // all 40 samples; four samples at a time travel as the four bytes of one word per coordinate, are broadcast
+        // inside the quad, and lane j assembles the key of sample 4r + j from byte j of the three words, probes the
+        // occupancy row and parks the key in the wave's LDS scratch.
+        //
+        // The reference returns the first sample with `key != previous and key in world`.  Membership is a function
+        // of the key alone and the world does not change during the march, so the FIRST SAMPLE IN THE WORLD always
+        // differs from its predecessor (which was not in the world): the hit is the earliest set membership bit.
+        // Each lane folds its ten bits into a mask; one group minimum of 4 * round + lane finds the sample; its
+        // key and the one before it (`previous`) are then read back from the scratch.
+        constexpr int ROUNDS = SAMPLES / 4;
+        const int a = G.gl & 3;
+        double c = a == 0 ? x : a == 1 ? y : z;
+        const double sc = div5(a == 0 ? vx : a == 1 ? vy : vz);  // dx / m with m = 5
+        const double magic = RINT_MAGIC + (a == 1 ? 4.0 : 6.0);
+        // byte selectors (v_perm_b32: 0-3 = bytes of the second source, 4-7 = bytes of the first, 0x0c = zero)
+        const unsigned sel_xy = 0x0c0c0000u | (unsigned)G.gl | ((4u + (unsigned)G.gl) << 8);
+        const unsigned sel_z = 0x0c000100u | ((4u + (unsigned)G.gl) << 16);
+        uint32_t* const mine = scratch + G.lane;
+        int kidx[ROUNDS];
+        uint32_t word[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            int w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                w |= clampi(__double2loint(c + magic), 0, 12) << (8 * j);
+                if (r * 4 + j + 1 < SAMPLES) c = c + sc;
+            }
+            const unsigned wx = (unsigned)dpp_quad<QUAD_BCAST0>(w), wy = (unsigned)dpp_quad<QUAD_BCAST1>(w),
+                           wz = (unsigned)dpp_quad<QUAD_BCAST2>(w);
+            // byte gl of wx, wy, wz -> bytes 0, 1, 2 of the key
+            const int key = (int)__builtin_amdgcn_perm(wz, __builtin_amdgcn_perm(wy, wx, sel_xy), sel_z);
+            kidx[r] = key_idx(key);
+            word[r] = occ_s[kidx[r] >> 5];  // all probes are issued before the first is consumed
+            mine[r * WAVE] = (uint32_t)key;
+        }
+        prio_at<PRIO, 2>(boost);
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = ROUNDS - 1; r >= 0; r--)
+            m = (m << 1) | __builtin_amdgcn_ubfe(word[r], (uint32_t)kidx[r], 1u);  // bit r: sample 4r + gl is in the world
+        const int first = G.group_min(m ? (__builtin_ctz(m) << 2) | a : SAMPLES);
+        wave_sync();
+        if (first < SAMPLES) {
+            uint32_t* const quad = scratch + (G.lane & ~3);
+            const int before = first > 0 ? first - 1 : 0;
+            const int bk = (int)quad[(first >> 2) * WAVE + (first & 3)];
+            const int pk = (int)quad[(before >> 2) * WAVE + (before & 3)];
+            h.hit = true;
+            h.have_prev = first != 0;
+            key_unpack(bk, h.bx, h.by, h.bz);
+            key_unpack(pk, h.px, h.py, h.pz);
+        }
+        return h;
+    }
+    const double sx = div5(vx), sy = div5(vy), sz = div5(vz);  // dx / m with m = 5
     if constexpr (GS == 1) {
         // one lane per env: the reference loop as is; stop when every active lane has its answer
         int q = 0, bk = 0, pk = 0;
@@ -544,61 +603,6 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
         }
         key_unpack(bk, h.bx, h.by, h.bz);
         key_unpack(pk, h.px, h.py, h.pz);
-        return h;
-    } else if constexpr (GS == 4) {
-        // Coordinate split: lane 0 / 1 / 2 of the group carries the x / y / z recurrence alone (39 sequential
-        // adds instead of 117 per lane) and rounds + clamps its coordinate of all 40 samples; four samples at
-        // a time travel as the four bytes of one word per coordinate, are broadcast inside the quad, and lane
-        // j assembles the key of sample 4r + j from byte j of the three words and tests it.
-        constexpr int ROUNDS = SAMPLES / 4;
-        const int a = G.gl & 3;
-        double c = a == 0 ? x : a == 1 ? y : z;
-        const double sc = a == 0 ? sx : a == 1 ? sy : sz;
-        const double magic = RINT_MAGIC + (a == 1 ? 4.0 : 6.0);
-        // byte selectors (v_perm_b32: 0-3 = bytes of the second source, 4-7 = bytes of the first, 0x0c = zero)
-        const unsigned sel_xy = 0x0c0c0000u | (unsigned)G.gl | ((4u + (unsigned)G.gl) << 8);
-        const unsigned sel_z = 0x0c000100u | ((4u + (unsigned)G.gl) << 16);
-        int key[ROUNDS];
-        uint32_t word[ROUNDS];
-#pragma unroll
-        for (int r = 0; r < ROUNDS; r++) {
-            int w = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                w |= clampi(__double2loint(c + magic), 0, 12) << (8 * j);
-                if (r * 4 + j + 1 < SAMPLES) c = c + sc;
-            }
-            const unsigned wx = (unsigned)dpp_quad<QUAD_BCAST0>(w), wy = (unsigned)dpp_quad<QUAD_BCAST1>(w),
-                           wz = (unsigned)dpp_quad<QUAD_BCAST2>(w);
-            // byte gl of wx, wy, wz -> bytes 0, 1, 2 of the key
-            key[r] = (int)__builtin_amdgcn_perm(wz, __builtin_amdgcn_perm(wy, wx, sel_xy), sel_z);
-            word[r] = occ_s[key_idx(key[r]) >> 5];  // all probes are issued before the first is consumed
-        }
-        prio_at<PRIO, 2>(boost);
-        // `key != previous and key in world`, first sample wins: every lane scans its own samples (previous =
-        // the neighbouring lane's key of the same round, or lane 3's key of the round before); sample number
-        // and key share one word, so one group minimum yields the earliest candidate and its key.
-        int best = SAMPLES << 24, bprev = SAMPLES << 24;
-        const int gtag = G.gl << 24;
-#pragma unroll
-        for (int r = ROUNDS - 1; r >= 0; r--) {  // descending, so the earliest candidate wins
-            // previous sample's key: lane j-1's key of this round, for lane 0 lane 3's key of the round before
-            // (lane 3 offers that one, then one rotation of the quad delivers both)
-            const int offer = (r > 0 && G.gl == 3) ? key[r - 1] : key[r];
-            const int q = dpp_quad<0x93>(offer);  // quad_perm [3, 0, 1, 2]
-            const bool inw = (word[r] >> (key_idx(key[r]) & 31)) & 1u;
-            const bool cand = ((r == 0 && G.gl == 0) || key[r] != q) && inw;
-            const int tag = gtag | ((r * 4) << 24);  // sample number 4r + j above the 24 key bits
-            if (cand) { best = tag | key[r]; bprev = tag | q; }
-        }
-        best = G.group_min(best);
-        bprev = G.group_min(bprev);
-        if ((best >> 24) < SAMPLES) {
-            h.hit = true;
-            h.have_prev = (best >> 24) != 0;
-            key_unpack(best & 0xffffff, h.bx, h.by, h.bz);
-            key_unpack(bprev & 0xffffff, h.px, h.py, h.pz);
-        }
         return h;
     } else {
         // Sample split.  Groups of 2: lane j owns the contiguous samples j*C .. j*C+C-1 (it first walks to its

@@ -289,7 +289,7 @@ template <int GS, int MODE, bool PRIO = false>
 __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
                                        const int8_t* grid_g, const TrigCtx& trig, double s0, double s1, double dy,
                                        int inventory, double cam0, double cam1, bool remove, bool add, Motion& mv,
-                                       bool boost = false) {
+                                       bool boost = false, uint32_t* scratch = nullptr) {
     constexpr bool FLY = MODE == MODE_FLY;
     CellChange ch;
     ch.idx = -1; ch.bit = 0; ch.old_val = 0; ch.new_val = 0;
@@ -354,7 +354,7 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
     if (want_sight) {
         // m = cos(radians(y)); dy = sin(radians(y)); dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
         const double vx = cy * cp, vy = sp, vz = sy * cp;
-        const Hit h = hit_test<GS, PRIO>(G, occ_s, e.x, e.y, e.z, vx, vy, vz, boost);
+        const Hit h = hit_test<GS, PRIO>(G, occ_s, e.x, e.y, e.z, vx, vy, vz, boost, scratch);
         if (add) {
             if (h.hit && h.have_prev) {
                 if (inv_get(e.inv, e.active - 1) > 0 && build_zone_i(h.px, h.py, h.pz)) {
@@ -519,6 +519,10 @@ struct WaveScratch {
     uint32_t items[ITEMS_MAX];  // compacted (target cell, changed env) matches of one chunk, see resolve_changes
 };
 
+template <int GS>
+struct BlockShared;
+// (the ray march of four-lane groups parks WAVE x 10 keys in the wave's histogram rows, which are idle then)
+static_assert(req_chunk<4>() * (HIST_ROW / 2) >= WAVE * 10, "hit_test scratch");
 template <int GS>
 struct BlockShared {
     static constexpr int EPB = BLOCK / GS;  // envs per block
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     if (MODE == MODE_WALK) {
         const WalkAct w = parse_walking_discrete(ra.action);
         ch = world_act<GS, MODE_WALK, true>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
-                                      w.remove, w.add, mv, boost);
+                                      w.remove, w.add, mv, boost, sh.ws[wave].hist[0]);
     } else if (MODE == MODE_WALK_DICT) {  // parse_walking_action, core/world.py:396-414
         const uint2 bw = ra.buttons;
         const bool fwd = bw.x & 0xffu, back = bw.x & 0xff00u, left = bw.x & 0xff0000u, right = bw.x & 0xff000000u;
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
         const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
         ch = world_act<GS, MODE_WALK_DICT, true>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
-                                           attack, use, mv, boost);
+                                           attack, use, mv, boost, sh.ws[wave].hist[0]);
     } else {  // parse_flying_action, core/world.py:416-432
         if constexpr (FLY_SPREAD) fly_fields(ra);
         const int placement = ra.placement;
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         }
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
         ch = world_act<GS, MODE_FLY, true>(G, p, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
-                                     placement == 2, placement == 1, mv, boost);
+                                     placement == 2, placement == 1, mv, boost, sh.ws[wave].hist[0]);
     }
     // issued here, consumed after the histogram update
     int start_val = 0, env_max_int = 0;
@@ -1126,7 +1130,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(KParams p, long long T, 
                                           : rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
             const WalkAct w = parse_walking_discrete(action);
             ch = world_act<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
-                                          w.remove, w.add, mv);
+                                          w.remove, w.add, mv, false, sh.ws[wave].hist[0]);
             if (ch.idx >= 0 && has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
         }
         const bool changed = active && ch.idx >= 0;
