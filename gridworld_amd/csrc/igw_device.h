@@ -468,23 +468,23 @@ __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* o
     double pa = ax ? px : az ? pz : py;
     const double na = (double)(ax ? nx : az ? nz : ny);
     double vy = e.vy;
-    const int i1 = ax ? -1 : 1;          // first face of the axis: (0,1,0), (-1,0,0), (0,0,1); the second is -i1
-    const double f1 = ax ? -1.0 : 1.0, f2 = ax ? 1.0 : -1.0;
-    // the four probe cells differ from np only along this lane's axis (and one level down): the x and z terms
-    // of the index take two values each, the level term four
-    const int xa = (clampi(nx + ux * i1, -6, 6) + 6) * 13, xb = (clampi(nx - ux * i1, -6, 6) + 6) * 13;
-    const int za = clampi(nz + uz * i1, -6, 6) + 6 + OCC_IDX0, zb = clampi(nz - uz * i1, -6, 6) + 6 + OCC_IDX0;
+    // The reference tries both faces of an axis in turn, (0,1,0) before (0,-1,0), (-1,0,0) before (1,0,0), (0,0,1)
+    // before (0,0,-1), each with d = (p - np) * f and `d < PAD => skip`.  |p - np| <= 0.5, so d >= PAD can hold for
+    // ONE of the two faces only -- the one on the side of the cell centre the agent is on -- and after its push
+    // d is exactly -PAD for the other: only that face is probed (two cells, one level apart), same arithmetic.
+    const double sgn = pa - na;
+    const bool pos = sgn > 0.0;                  // the face with f = +1 along this axis, else f = -1
+    const int i1 = pos ? 1 : -1;
+    const double f1 = pos ? 1.0 : -1.0;
+    // the two probe cells differ from np only along this lane's axis (and one level down)
+    const int xa = (clampi(nx + ux * i1, -6, 6) + 6) * 13;
+    const int za = clampi(nz + uz * i1, -6, 6) + 6 + OCC_IDX0;
     const int ya0 = (clampi(ny + uy * i1, -4, 8) + 4) * OCC_LAYER, ya1 = (clampi(ny + uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
-    const int yb0 = (clampi(ny - uy * i1, -4, 8) + 4) * OCC_LAYER, yb1 = (clampi(ny - uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
     const bool b1 = (int)occ_test(occ_s, ya0 + xa + za) | (int)occ_test(occ_s, ya1 + xa + za);
-    const bool b2 = (int)occ_test(occ_s, yb0 + xb + zb) | (int)occ_test(occ_s, yb1 + xb + zb);
-    double d = (pa - na) * f1;
+    const double d = sgn * f1;
     const bool h1 = !(d < PAD) && b1;
     pa = h1 ? pa - (d - PAD) * f1 : pa;
-    d = (pa - na) * f2;
-    const bool h2 = !(d < PAD) && b2;
-    pa = h2 ? pa - (d - PAD) * f2 : pa;
-    if (uy && (h1 || h2)) vy = 0.0;
+    if (uy && h1) vy = 0.0;
     py = dpp_quad<QUAD_BCAST0>(pa);
     px = dpp_quad<QUAD_BCAST1>(pa);
     pz = dpp_quad<QUAD_BCAST2>(pa);
