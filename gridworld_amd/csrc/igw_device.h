@@ -607,9 +607,7 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
     } else {
         // Sample split.  Groups of 2: lane j owns the contiguous samples j*C .. j*C+C-1 (it first walks to its
         // chunk -- the reference's recurrence, nothing can be skipped).  Wider groups: lane j owns samples
-        // j, j+GS, ... (every round after the first advances all lanes by GS unmasked adds).  `previous` of a
-        // lane's sample is the neighbouring sample's key (one shuffle); the first `key != previous and key in
-        // world` of the whole ray is a per-lane scan plus one group minimum.
+        // j, j+GS, ... (every round after the first advances all lanes by GS unmasked adds).
         constexpr bool CHUNKED = GS == 2;
         constexpr int C = (SAMPLES + GS - 1) / GS;  // samples per lane (chunked) = rounds (strided)
         int key[C];
@@ -643,29 +641,24 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
                 inw[r] = occ_test(occ_s, key_idx(key[r]));
             }
         }
-        int first = SAMPLES, fkey = 0, fprev = 0;
+        // The hit is the first sample in the world (it always differs from its predecessor, see the four-lane path):
+        // every lane finds its earliest one, a group minimum names the sample, and its key and the key of the sample
+        // before it are fetched from their owners.
+        int first = SAMPLES, fkey = 0;
 #pragma unroll
-        for (int k = C - 1; k >= 0; k--) {  // descending, so the earliest candidate wins
-            int s, prev;
-            if constexpr (CHUNKED) {
-                s = G.gl * C + k;
-                const int q = G.shfl_up1(key[C - 1]);  // last key of the previous lane's chunk
-                prev = (k == 0) ? q : key[k - 1];
-            } else {
-                s = k * GS + G.gl;
-                prev = G.shfl_up1(key[k]);
-                if (k > 0) {
-                    const int wrap = G.bcast_last(key[k - 1]);
-                    if (G.gl == 0) prev = wrap;
-                }
-            }
-            const bool cand = s < SAMPLES && ((s == 0) || key[k] != prev) && inw[k];
-            if (cand) { first = s; fkey = key[k]; fprev = prev; }
+        for (int k = C - 1; k >= 0; k--) {  // descending, so the earliest wins
+            const int s = CHUNKED ? G.gl * C + k : k * GS + G.gl;
+            if (s < SAMPLES && inw[k]) { first = s; fkey = key[k]; }
         }
         const int best = G.group_min(first);
         if (best < SAMPLES) {
-            const int owner = CHUNKED ? best / C : best % GS;
-            const int bk = G.bcast(fkey, owner), pk = G.bcast(fprev, owner);
+            const int before = best > 0 ? best - 1 : 0;
+            const int owner = CHUNKED ? best / C : best % GS, owner_b = CHUNKED ? before / C : before % GS;
+            const int slot_b = CHUNKED ? before % C : before / GS;  // where the owner of `before` keeps it
+            int bkey = key[0];
+#pragma unroll
+            for (int k = 1; k < C; k++) bkey = (k == slot_b) ? key[k] : bkey;
+            const int bk = G.bcast(fkey, owner), pk = G.bcast(bkey, owner_b);
             h.hit = true;
             h.have_prev = best != 0;
             key_unpack(bk, h.bx, h.by, h.bz);
