@@ -890,6 +890,77 @@ __device__ inline void write_trajectory(const KParams& p, const ActIn& a, int en
         *reinterpret_cast<int4*>(p.traj_heads + ((size_t)env * 2 + ((ep + 1) & 1)) * 4) = make_int4(task_next, 0, (int)(ep + 1), 0);
 }
 
+
+// The kernel parameters as the launch's kernarg segment, behind a pointer the compiler cannot see through: code
+// that reads them through it loads what it needs where it needs it (scalar loads from the constant cache) instead
+// of keeping everything it will need at the END of the step in scalar registers from the START (the step kernel
+// ran out of them and parked 29 in vector-register lanes: v_writelane / v_readlane are vector-ALU instructions).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline const KParams& kernarg_again(const KParams&) {
+    typedef __attribute__((address_space(4))) const KParams kparams_c;
+    kparams_c* ka = (kparams_c*)__builtin_amdgcn_kernarg_segment_ptr();  // KParams is the first argument
+    asm volatile("" : "+s"(ka));
+    return *(const KParams*)ka;
+}
+#else
+__device__ inline const KParams& kernarg_again(const KParams& p) { return p; }
+#endif
+
+// The end of a step: reward / done, the in-step reset, the last stores.
+template <int GS, int MODE, bool EXTRA>
+__device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn& a, BlockShared<GS>& sh, int wave, int env,
+                                 bool active, Env& e, const CellChange& ch, int task, int env_max_int, int size_new, int mi,
+                                 bool need, bool changed, int8_t* grid_g, const uint32_t* occ_s, bool boost) {
+    const StepOut o = finish_step(p, e, env_max_int, size_new, mi);
+    const bool do_reset = active && o.done && p.autoreset;
+    uint32_t ep = 0;
+    const int task_old = task;
+    int generated_size = -1;
+    bool has_start = false;
+    const TaskMeta* meta = nullptr;
+    if (do_reset) {
+        ep = next_task(p, env, G.gl == 0, task);  // the next episode's task (task generators on the device)
+        meta = p.task_meta + task;
+        has_start = !p.rt_enabled && meta->has_start != 0;
+    }
+    resolve_resets<GS, EXTRA>(G, p, do_reset, env, task, has_start, ep, nullptr,
+                              reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
+    prio_at<true, 7>(boost);
+#ifdef IGW_DIAG
+    {
+        const unsigned long long n_ch = __builtin_popcountll(__ballot(changed && G.gl == 0));
+        const unsigned long long n_rt = __builtin_popcountll(__ballot(do_reset && G.gl == 0));
+        const unsigned long long n_hit = __builtin_popcountll(__ballot(ch.idx >= 0 && ch.new_val == 0 && G.gl == 0));
+        stamp_features(p, n_ch | (n_rt << 16) | ((unsigned long long)wave_max_i32(diag_m) << 24) | (n_hit << 32));
+    }
+#endif
+    if (!active) return;
+    if constexpr (EXTRA) {
+        if (p.traj && env < p.traj_n && G.gl == 0) {
+            const uint32_t ep_now = do_reset ? ep : __hip_atomic_load(p.episode + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            write_trajectory<MODE>(p, a, env, task_old, ep_now, e, ch, o, do_reset, task);
+        }
+    }
+    if (do_reset) reset_env_regs(e, meta, false, generated_size);
+    if (G.gl == 0) {
+        if (ch.idx >= 0 && !do_reset) {
+            grid_g[ch.idx] = (int8_t)ch.new_val;
+            p.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = occ_s[OCC_VAR0 + (ch.bit >> 5)];
+        }
+        if (!IGW_DIAG_FLAG(p, 16)) {  // diag 16: what the output stores cost
+            st(p.reward + env, (float)o.reward);
+            st(p.done + env, (uint8_t)(o.done ? 1 : 0));
+            if (do_reset) write_reset_obs(p, env, e);
+        }
+        if (do_reset) env_store_pose(e, p.agent + env);
+        env_store_counters(e, p.agent + env);
+        if (need) stat_add(p.stats, IGW_STAT_CHANGED, 1);
+        if (ch.idx >= 0) stat_add(p.stats, IGW_STAT_RESCANS, 1);
+        if (do_reset) stat_add(p.stats, IGW_STAT_RESETS, 1);
+    }
+    stamp(p, 6);
+}
+
 // __launch_bounds__(BLOCK, 4): four waves per SIMD, i.e. at most 128 VGPRs -- the whole 65,536-env batch at four
 // lanes per env is then co-resident (4,096 waves = 4 per SIMD) and runs in one round.
 // EXTRA: the RandomTasks generator and the episode log are compiled in (launched only when one of them is enabled,
@@ -1023,54 +1094,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     }
     stamp(p, 5);
     prio_at<true, 6>(boost);
-    const StepOut o = finish_step(p, e, env_max_int, size_new, mi);
-    const bool do_reset = active && o.done && p.autoreset;
-    uint32_t ep = 0;
-    const int task_old = task;
-    int generated_size = -1;
-    bool has_start = false;
-    const TaskMeta* meta = nullptr;
-    if (do_reset) {
-        ep = next_task(p, env, G.gl == 0, task);  // the next episode's task (task generators on the device)
-        meta = p.task_meta + task;
-        has_start = !p.rt_enabled && meta->has_start != 0;
-    }
-    resolve_resets<GS, EXTRA>(G, p, do_reset, env, task, has_start, ep, nullptr,
-                              reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
-    prio_at<true, 7>(boost);
-#ifdef IGW_DIAG
-    {
-        const unsigned long long n_ch = __builtin_popcountll(__ballot(changed && G.gl == 0));
-        const unsigned long long n_rt = __builtin_popcountll(__ballot(do_reset && G.gl == 0));
-        const unsigned long long n_hit = __builtin_popcountll(__ballot(ch.idx >= 0 && ch.new_val == 0 && G.gl == 0));
-        stamp_features(p, n_ch | (n_rt << 16) | ((unsigned long long)wave_max_i32(diag_m) << 24) | (n_hit << 32));
-    }
-#endif
-    if (!active) return;
-    if constexpr (EXTRA) {
-        if (p.traj && env < p.traj_n && G.gl == 0) {
-            const uint32_t ep_now = do_reset ? ep : __hip_atomic_load(p.episode + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            write_trajectory<MODE>(p, a, env, task_old, ep_now, e, ch, o, do_reset, task);
-        }
-    }
-    if (do_reset) reset_env_regs(e, meta, false, generated_size);
-    if (G.gl == 0) {
-        if (ch.idx >= 0 && !do_reset) {
-            grid_g[ch.idx] = (int8_t)ch.new_val;
-            p.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = occ_s[OCC_VAR0 + (ch.bit >> 5)];
-        }
-        if (!IGW_DIAG_FLAG(p, 16)) {  // diag 16: what the output stores cost
-            st(p.reward + env, (float)o.reward);
-            st(p.done + env, (uint8_t)(o.done ? 1 : 0));
-            if (do_reset) write_reset_obs(p, env, e);
-        }
-        if (do_reset) env_store_pose(e, p.agent + env);
-        env_store_counters(e, p.agent + env);
-        if (need) stat_add(p.stats, IGW_STAT_CHANGED, 1);
-        if (ch.idx >= 0) stat_add(p.stats, IGW_STAT_RESCANS, 1);
-        if (do_reset) stat_add(p.stats, IGW_STAT_RESETS, 1);
-    }
-    stamp(p, 6);
+    // (KParams must stay the kernel's FIRST parameter: kernarg_again reads it at offset 0 of the kernarg segment)
+    tail_step<GS, MODE, EXTRA>(G, kernarg_again(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost);
 }
 
 // T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
