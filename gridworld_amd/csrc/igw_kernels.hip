@@ -910,7 +910,8 @@ __device__ inline const KParams& kernarg_again(const KParams& p) { return p; }
 template <int GS, int MODE, bool EXTRA>
 __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn& a, BlockShared<GS>& sh, int wave, int env,
                                  bool active, Env& e, const CellChange& ch, int task, int env_max_int, int size_new, int mi,
-                                 bool need, bool changed, int8_t* grid_g, const uint32_t* occ_s, bool boost) {
+                                 bool need, bool changed, int8_t* grid_g, const uint32_t* occ_s, bool boost,
+                                 [[maybe_unused]] int diag_m) {
     const StepOut o = finish_step(p, e, env_max_int, size_new, mi);
     const bool do_reset = active && o.done && p.autoreset;
     uint32_t ep = 0;
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     stamp(p, 5);
     prio_at<true, 6>(boost);
     // (KParams must stay the kernel's FIRST parameter: kernarg_again reads it at offset 0 of the kernarg segment)
-    tail_step<GS, MODE, EXTRA>(G, kernarg_again(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost);
+    tail_step<GS, MODE, EXTRA>(G, kernarg_again(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m);
 }
 
 // T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
