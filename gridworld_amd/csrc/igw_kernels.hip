@@ -1147,6 +1147,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
     o.reward = 0.0; o.done = false;
     bool last_reset = false;
     for (long long t = 0; t < T; t++) {
+        // the parameters are read again from the kernarg segment in every phase of every step (see kernarg_again):
+        // held in scalar registers over the whole loop they did not fit (121 of them parked in vector lanes)
+        const KParams& p1 = kernarg_again(p);
         CellChange ch;
         ch.idx = -1; ch.bit = 0; ch.old_val = ch.new_val = 0;
         Motion mv = {0.0, 0.0, 0.0};
@@ -1154,20 +1157,21 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
         bool need = false;
         if (active) {
             e.step_no = min(e.step_no + 1, 65535);
-            const int action = io.actions ? io.actions[(size_t)t * p.n_envs + env]
+            const int action = io.actions ? io.actions[(size_t)t * p1.n_envs + env]
                                           : rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
             const WalkAct w = parse_walking_discrete(action);
-            ch = world_act<GS, MODE_WALK>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
+            ch = world_act<GS, MODE_WALK>(G, p1, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
                                           w.remove, w.add, mv, false, sh.ws[wave].hist[0]);
-            if (ch.idx >= 0 && has_start) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
+            if (ch.idx >= 0 && has_start) start_val = p1.task_start[(size_t)task * STRIDE + ch.idx];
         }
         const bool changed = active && ch.idx >= 0;
-        const uint64_t chg_mask = prefetch_changes<GS, true>(G, p, sh.ws[wave], changed, env, task, ch);
+        const KParams& p2 = kernarg_again(p);
+        const uint64_t chg_mask = prefetch_changes<GS, true>(G, p2, sh.ws[wave], changed, env, task, ch);
         if (active) {
-            world_update<GS, MODE_WALK>(G, p, e, occ_s, mv);
+            world_update<GS, MODE_WALK>(G, p2, e, occ_s, mv);
             finish_break(e, ch);
         }
-        const int hmax = resolve_changes<GS, true>(G, p, sh.ws[wave], chg_mask, env, task, ch);
+        const int hmax = resolve_changes<GS, true>(G, p2, sh.ws[wave], chg_mask, env, task, ch);
         if (active) {
             size_new = e.prev_size + syn_size_delta(ch, start_val);
             need = size_new != e.prev_size;
@@ -1181,16 +1185,17 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
                 e.dirty = 1;
             }
         }
+        const KParams& p3 = kernarg_again(p);
         bool do_reset = false;
         if (active) {
-            o = finish_step(p, e, env_max_int, size_new, mi);
+            o = finish_step(p3, e, env_max_int, size_new, mi);
             n_changed += need;
             n_updates += changed;
-            do_reset = o.done && (io.actions == nullptr || p.autoreset);
+            do_reset = o.done && (io.actions == nullptr || p3.autoreset);
             last_reset = do_reset;
             if (G.gl == 0) {
-                if (io.rewards) io.rewards[(size_t)t * p.n_envs + env] = (float)o.reward;
-                if (io.dones) io.dones[(size_t)t * p.n_envs + env] = o.done ? 1 : 0;
+                if (io.rewards) io.rewards[(size_t)t * p3.n_envs + env] = (float)o.reward;
+                if (io.dones) io.dones[(size_t)t * p3.n_envs + env] = o.done ? 1 : 0;
             }
             // colours go to HBM right away (a later break of this launch reads them)
             if (ch.idx >= 0 && !do_reset && G.gl == 0) grid_g[ch.idx] = (int8_t)ch.new_val;
@@ -1198,13 +1203,13 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
         uint32_t ep = 0;
         int generated_size = -1;
         if (active && do_reset) {
-            ep = next_task(p, env, G.gl == 0, task);
-            meta = p.task_meta + task;
-            has_start = !p.rt_enabled && meta->has_start != 0;
-            env_max_int = p.rt_enabled ? 0 : meta->env_max_int;
+            ep = next_task(p3, env, G.gl == 0, task);
+            meta = p3.task_meta + task;
+            has_start = !p3.rt_enabled && meta->has_start != 0;
+            env_max_int = p3.rt_enabled ? 0 : meta->env_max_int;
         }
         wave_sync();
-        resolve_resets<GS, true>(G, p, do_reset, env, task, has_start, ep, occ_wave_s,
+        resolve_resets<GS, true>(G, p3, do_reset, env, task, has_start, ep, occ_wave_s,
                                  reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
