@@ -57,15 +57,26 @@ def main():
         with_start = rng.rand() < 0.5
         T = int(rng.choice([30, 90]))
         tg, st = targets(rng, n, with_start)
-        desc = f'case {c}: n={n} gs={gs} {mode} autoreset={autoreset} start={with_start} {kw}'
+        # a third of the cases: arbitrary initial poses -- off the 5-degree lattice (general trig path, oracle in
+        # device-trig mode), up to the edge of the validated range (clamped occupancy keys, agents outside the zone)
+        poses = None
+        if rng.rand() < 0.33:
+            poses = np.stack([rng.uniform(-9.5, 9.5, n), np.where(rng.rand(n) < 0.8, rng.uniform(-0.25, 9.0, n), rng.uniform(-6.0, 30.0, n)),
+                              rng.uniform(-9.5, 9.5, n), rng.uniform(-400.0, 400.0, n), rng.uniform(-90.0, 90.0, n)], axis=1)
+            if rng.rand() < 0.5:   # half of them on the lattice, at the border
+                poses[:, 3:] = np.round(poses[:, 3:] / 5.0) * 5.0
+                poses[:, [0, 2]] = np.round(poses[:, [0, 2]] * 4.0) / 4.0
+        desc = f'case {c}: n={n} gs={gs} {mode} autoreset={autoreset} start={with_start} poses={poses is not None} {kw}'
         env = VecGridWorld(n, action_space=mode, autoreset=autoreset, lanes_per_env=gs, **kw)
-        env.set_tasks(tg, st)
+        env.set_tasks(tg, st, init_pose=poses)
         env.reset()
         ob = O.OracleBatch(n, action_space=mode, **kw)
         ob.set_tasks(tg, st)
+        if poses is not None:
+            ob.set_initial_pose(poses)
         ob.reset()
         try:
-            O.use_device_trig(mode == 'flying')
+            O.use_device_trig(mode == 'flying' or poses is not None)
             fused = mode == 'walking' and c % 3 == 0   # every third walking case: chunks through the fused replay
             t = 0
             while fused and t < T:
