@@ -230,7 +230,8 @@ def main():
 
     # actions for pre-roll, warmup and the timed steps are generated on the device before the clock starts
     if flying:
-        args.no_fused = True  # the fused rollout kernel is walking-only
+        fly_fused = not args.no_fused
+        args.no_fused = True  # the fused rollout with in-kernel random actions is walking-only
         from gridworld_amd import _lib as L
 
         def fly_actions(n_steps):
@@ -401,6 +402,19 @@ def main():
         gdist.barrier(device)
         t0 = time.perf_counter()
         env.rollout_actions(actions[0])
+        torch.cuda.synchronize(device)
+        gdist.barrier(device)
+        r_steps, r_el = gdist.reduce_window(N * Tr, time.perf_counter() - t0, device)
+        fused_rec = r_steps / r_el
+
+    if flying and fly_fused:   # the fused loop over the recorded flying actions (igw_rollout_flying_actions)
+        rec = dict(movement=acts[0], camera=acts[1], inventory=acts[2], placement=acts[3])
+        Tr = acts[0].shape[0]
+        env.rollout_actions(rec)  # warm
+        torch.cuda.synchronize(device)
+        gdist.barrier(device)
+        t0 = time.perf_counter()
+        env.rollout_actions(rec)
         torch.cuda.synchronize(device)
         gdist.barrier(device)
         r_steps, r_el = gdist.reduce_window(N * Tr, time.perf_counter() - t0, device)

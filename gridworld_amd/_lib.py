@@ -27,7 +27,7 @@ RESET_KEEP_SIZE = 1
 EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',
            'igw_bind_buffers', 'igw_prepare_tasks', 'igw_set_task_sampling', 'igw_set_random_tasks',
            'igw_set_trajectory_log', 'igw_reset', 'igw_step_walking', 'igw_step_flying', 'igw_step_walking_dict',
-           'igw_rollout_walking', 'igw_rollout_walking_actions', 'igw_fill_actions_walking', 'igw_task_eval']
+           'igw_rollout_walking', 'igw_rollout_walking_actions', 'igw_rollout_flying_actions', 'igw_fill_actions_walking', 'igw_task_eval']
 
 
 class IgwError(RuntimeError):
@@ -91,6 +91,7 @@ def load(build_if_missing=True):
     L.igw_step_walking_dict.argtypes = [vp, vp, vp, vp]
     L.igw_rollout_walking.argtypes = [vp, i64, u64, i64, i64, vp]
     L.igw_rollout_walking_actions.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.igw_rollout_flying_actions.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp]
     L.igw_fill_actions_walking.argtypes = [vp, vp, i64, i64, u64, i64, vp]
     L.igw_task_eval.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:

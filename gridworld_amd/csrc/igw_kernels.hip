@@ -1106,10 +1106,15 @@ struct RolloutIO {
     const int32_t* actions;
     float* rewards;
     uint8_t* dones;
+    // flying (igw_rollout_flying_actions): [T][N][3], [T][N][2], [T][N], [T][N]
+    const float* movement;
+    const float* camera;
+    const int32_t* inventory;
+    const int32_t* placement;
 };
 // __launch_bounds__(BLOCK, 3): left alone the loop keeps 196 registers live (2 waves per SIMD); three waves per SIMD
 // (168 registers, 5 spilled dwords) measured fastest: 6.1 G against 5.4 G; four (128, 39 spilled) 5.9 G.
-template <int GS>
+template <int GS, int MODE = MODE_WALK>
 __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KParams p, long long T, unsigned long long seed,
                                                         long long t0, long long env_offset, RolloutIO io) {
     __shared__ BlockShared<GS> sh;
@@ -1157,18 +1162,35 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
         bool need = false;
         if (active) {
             e.step_no = min(e.step_no + 1, 65535);
-            const int action = io.actions ? io.actions[(size_t)t * p1.n_envs + env]
-                                          : rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
-            const WalkAct w = parse_walking_discrete(action);
-            ch = world_act<GS, MODE_WALK>(G, p1, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
-                                          w.remove, w.add, mv, false, sh.ws[wave].hist[0]);
+            if constexpr (MODE == MODE_FLY) {  // parse_flying_action, core/world.py:416-432 (as in step_kernel)
+                const size_t at = (size_t)t * p1.n_envs + env;
+                const int placement = io.placement[at];
+                int inventory = io.inventory[at];
+                double f[5] = {(double)io.movement[3 * at], (double)io.movement[3 * at + 1], (double)io.movement[3 * at + 2],
+                               (double)io.camera[2 * at], (double)io.camera[2 * at + 1]};
+                bool bad = false;
+                if ((unsigned)inventory > 6u) { inventory = 0; bad = true; }
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    if (!__builtin_isfinite(f[i])) { f[i] = 0.0; bad = true; }
+                }
+                if (bad && G.gl == 0) stat_add(p1.stats, IGW_STAT_BAD_ACTION, 1);
+                ch = world_act<GS, MODE_FLY>(G, p1, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
+                                             placement == 2, placement == 1, mv, false, sh.ws[wave].hist[0]);
+            } else {
+                const int action = io.actions ? io.actions[(size_t)t * p1.n_envs + env]
+                                              : rng_action18(seed, (uint64_t)(env_offset + env), (uint64_t)(t0 + t));
+                const WalkAct w = parse_walking_discrete(action);
+                ch = world_act<GS, MODE_WALK>(G, p1, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
+                                              w.remove, w.add, mv, false, sh.ws[wave].hist[0]);
+            }
             if (ch.idx >= 0 && has_start) start_val = p1.task_start[(size_t)task * STRIDE + ch.idx];
         }
         const bool changed = active && ch.idx >= 0;
         const KParams& p2 = kernarg_again(p);
         const uint64_t chg_mask = prefetch_changes<GS, true>(G, p2, sh.ws[wave], changed, env, task, ch);
         if (active) {
-            world_update<GS, MODE_WALK>(G, p2, e, occ_s, mv);
+            world_update<GS, MODE>(G, p2, e, occ_s, mv);
             finish_break(e, ch);
         }
         const int hmax = resolve_changes<GS, true>(G, p2, sh.ws[wave], chg_mask, env, task, ch);
@@ -1191,7 +1213,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
             o = finish_step(p3, e, env_max_int, size_new, mi);
             n_changed += need;
             n_updates += changed;
-            do_reset = o.done && (io.actions == nullptr || p3.autoreset);
+            do_reset = o.done && ((MODE == MODE_WALK && io.actions == nullptr) || p3.autoreset);
             last_reset = do_reset;
             if (G.gl == 0) {
                 if (io.rewards) io.rewards[(size_t)t * p3.n_envs + env] = (float)o.reward;
@@ -1733,7 +1755,7 @@ int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int6
     if (T == 0) return IGW_OK;
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(rollout_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, (long long)T, (unsigned long long)seed,
-                                            (long long)t0, (long long)env_offset, RolloutIO{nullptr, nullptr, nullptr}));
+                                            (long long)t0, (long long)env_offset, RolloutIO{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}));
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1746,7 +1768,20 @@ int igw_rollout_walking_actions(igw_ctx* ctx, const int32_t* actions, int64_t T,
     if (T == 0) return IGW_OK;
     DISPATCH_GS(ctx->gs, hipLaunchKernelGGL(rollout_kernel<GS>, dim3(env_blocks(ctx)), dim3(BLOCK), 0,
                                             (hipStream_t)stream, ctx->kp, (long long)T, 0ull, 0ll, 0ll,
-                                            RolloutIO{actions, rewards, dones}));
+                                            RolloutIO{actions, rewards, dones, nullptr, nullptr, nullptr, nullptr}));
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_rollout_flying_actions(igw_ctx* ctx, const float* movement, const float* camera, const int32_t* inventory,
+                               const int32_t* placement, int64_t T, float* rewards, uint8_t* dones, void* stream) {
+    CHECK_CTX("igw_rollout_flying_actions");
+    if (ctx->cfg.action_space != IGW_FLYING) return fail(IGW_ERR_INVALID, "igw_rollout_flying_actions: context was created for another action space");
+    if (T < 0 || (T > 0 && (!movement || !camera || !inventory || !placement))) return fail(IGW_ERR_INVALID, "igw_rollout_flying_actions: bad argument");
+    if (T == 0) return IGW_OK;
+    DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((rollout_kernel<GS, MODE_FLY>), dim3(env_blocks(ctx)), dim3(BLOCK), 0,
+                                            (hipStream_t)stream, ctx->kp, (long long)T, 0ull, 0ll, 0ll,
+                                            RolloutIO{nullptr, rewards, dones, movement, camera, inventory, placement}));
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }

@@ -282,23 +282,42 @@ class VecGridWorld:
                                              self._stream()), 'igw_rollout_walking')
 
     def rollout_actions(self, actions, return_rewards=False):
-        """Fused replay of a recorded action sequence: `actions` int32 [T, N] (Discrete(18) ids) -- bit-identical to
+        """Fused replay of a recorded action sequence: `actions` int32 [T, N] (Discrete(18) ids), or for the flying action
+        space a dict of [T, N, ...] arrays (movement, camera, inventory, placement) -- bit-identical to
         T calls of step(), in one launch without a barrier between the steps of different envs (the context's
         autoreset setting applies).  With return_rewards: (rewards float32 [T, N], dones uint8 [T, N])."""
         self._need_tasks()
-        a = torch.as_tensor(actions, device=self.device)
-        if a.dim() != 2 or a.shape[1] != self.num_envs:
-            raise ValueError(f'actions must be [T, {self.num_envs}], got {tuple(a.shape)}')
-        a = a.to(torch.int32).contiguous()
-        T = a.shape[0]
+        N, dev = self.num_envs, self.device
+        if self.walk_dict:
+            raise L.IgwError('rollout_actions: Discrete(18) walking and flying only')
+        if self.flying:   # dict(movement f32[T,N,3], camera f32[T,N,2], inventory i32[T,N], placement i32[T,N])
+            mv = torch.as_tensor(actions['movement'], device=dev).to(torch.float32).contiguous()
+            cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).contiguous()
+            inv = torch.as_tensor(actions['inventory'], device=dev).to(torch.int32).contiguous()
+            plc = torch.as_tensor(actions['placement'], device=dev).to(torch.int32).contiguous()
+            T = mv.shape[0]
+            if tuple(mv.shape) != (T, N, 3) or tuple(cam.shape) != (T, N, 2) or tuple(inv.shape) != (T, N) or tuple(plc.shape) != (T, N):
+                raise ValueError(f'flying actions must be [T,{N},3], [T,{N},2], [T,{N}], [T,{N}]')
+            keep = (mv, cam, inv, plc)
+        else:
+            a = torch.as_tensor(actions, device=dev)
+            if a.dim() != 2 or a.shape[1] != N:
+                raise ValueError(f'actions must be [T, {N}], got {tuple(a.shape)}')
+            a = a.to(torch.int32).contiguous()
+            T = a.shape[0]
+            keep = (a,)
         rw = dn = None
         if return_rewards:
-            rw = torch.empty((T, self.num_envs), dtype=torch.float32, device=self.device)
-            dn = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
-        L.check(self.lib.igw_rollout_walking_actions(self.ctx, a.data_ptr(), int(T), rw.data_ptr() if rw is not None else None,
-                                                     dn.data_ptr() if dn is not None else None, self._stream()),
-                'igw_rollout_walking_actions')
-        self._keep = a  # the launch reads it asynchronously
+            rw = torch.empty((T, N), dtype=torch.float32, device=dev)
+            dn = torch.empty((T, N), dtype=torch.uint8, device=dev)
+        rp, dp = (rw.data_ptr() if rw is not None else None), (dn.data_ptr() if dn is not None else None)
+        if self.flying:
+            L.check(self.lib.igw_rollout_flying_actions(self.ctx, mv.data_ptr(), cam.data_ptr(), inv.data_ptr(), plc.data_ptr(),
+                                                        int(T), rp, dp, self._stream()), 'igw_rollout_flying_actions')
+        else:
+            L.check(self.lib.igw_rollout_walking_actions(self.ctx, a.data_ptr(), int(T), rp, dp, self._stream()),
+                    'igw_rollout_walking_actions')
+        self._keep = keep  # the launch reads them asynchronously
         return (rw, dn) if return_rewards else None
 
     def fill_actions(self, n_steps, seed, t0=0, env_offset=0):

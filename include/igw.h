@@ -15,7 +15,7 @@
  *   igw_step_walking_dict <- same with parse_walking_action, discretize=False (core/world.py:396-414)
  *   igw_task_eval      <- Task.maximal_intersection / argmax_intersection
  *                         (tasks/task.py:121-161)
- *   igw_rollout_walking, igw_rollout_walking_actions <- the loop of examples/run_env.py:18-26 fused on device
+ *   igw_rollout_walking, igw_rollout_walking_actions, igw_rollout_flying_actions <- the loop of examples/run_env.py:18-26 fused on device
  *
  * Plain pointers and sizes only; every data pointer is a DEVICE pointer owned by
  * the caller (e.g. torch tensors) and must outlive the context.  All calls are
@@ -234,6 +234,10 @@ int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int6
  * <- the loop of examples/run_env.py:18-26 over a recorded action sequence.  Not with the episode log. */
 int igw_rollout_walking_actions(igw_ctx* ctx, const int32_t* actions, int64_t T, float* rewards, uint8_t* dones,
                                 void* stream);
+/* ... and for the flying action space: movement float [T][N][3], camera float [T][N][2], inventory / placement
+ * int32 [T][N]; exactly T calls of igw_step_flying. */
+int igw_rollout_flying_actions(igw_ctx* ctx, const float* movement, const float* camera, const int32_t* inventory,
+                               const int32_t* placement, int64_t T, float* rewards, uint8_t* dones, void* stream);
 /* fills actions[n_steps][N] with the same counter RNG (t = t0 .. t0+n_steps-1) */
 int igw_fill_actions_walking(igw_ctx* ctx, int32_t* actions, int64_t n_steps, int64_t t0, uint64_t seed,
                              int64_t env_offset, void* stream);

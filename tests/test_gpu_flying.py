@@ -210,3 +210,42 @@ def test_flying_divergence_from_glibc_reference_at_scale(capsys):
     assert res['envs_with_integer_divergence'] <= S // 100      # < 1 % of episodes see any integer-output change
     assert res['envs_with_float32_obs_divergence'] <= S // 10   # float32 observations: < 10 % of episodes, last bit
     assert max_dev < 1e-6 or res['envs_with_integer_divergence'] > 0
+
+
+@pytest.mark.parametrize('autoreset', [True, False])
+@pytest.mark.parametrize('gs', [0, 4, 1])
+def test_flying_rollout_over_recorded_actions_equals_stepping(gs, autoreset):
+    """igw_rollout_flying_actions: T fused flying steps over the caller's actions == T calls of step(), per-step
+    rewards / dones and the complete final state (float64 internals included), bad actions counted alike."""
+    from gridworld_amd import VecGridWorld
+    n, T = 300, 180
+    rng = np.random.RandomState(9)
+    tg = np.zeros((n, 9, 11, 11), np.int8)
+    for e in range(n):
+        for _ in range(25):
+            tg[e, rng.randint(2), rng.randint(11), rng.randint(11)] = rng.randint(1, 7)
+    kw = dict(action_space='flying', size_reward=False, max_steps=70, autoreset=autoreset, lanes_per_env=gs)
+    acts = dict(movement=torch.as_tensor((rng.uniform(-1, 1, (T, n, 3)) * (rng.rand(T, n, 1) < 0.8)).astype(np.float32)),
+                camera=torch.as_tensor(rng.uniform(-12, 12, (T, n, 2)).astype(np.float32)),
+                inventory=torch.as_tensor(rng.randint(0, 7, (T, n)).astype(np.int32)),
+                placement=torch.as_tensor(rng.randint(0, 3, (T, n)).astype(np.int32)))
+    acts['camera'][5, 3, 0] = float('nan')   # a rejected component: runs as 0, counted
+    acts['inventory'][7, 9] = 9
+    a, b = VecGridWorld(n, **kw), VecGridWorld(n, **kw)
+    for env in (a, b):
+        env.set_tasks(tg)
+        env.reset()
+    acts = {k: v.to(a.device) for k, v in acts.items()}
+    rw, dn = a.rollout_actions(acts, return_rewards=True)
+    rw_b, dn_b = [], []
+    for t in range(T):
+        b.step({k: v[t] for k, v in acts.items()})
+        rw_b.append(b.reward.clone())
+        dn_b.append(b.done.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(rw.view(torch.int32), torch.stack(rw_b).view(torch.int32))
+    assert torch.equal(dn, torch.stack(dn_b))
+    for name in ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'agent_pos', 'inventory', 'compass', 'reward', 'done'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    sa, sb = a.stats(), b.stats()
+    assert sa['changed'] == sb['changed'] and sa['resets'] == sb['resets'] and sa['bad_actions'] == sb['bad_actions'] == 2
