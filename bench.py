@@ -8,37 +8,46 @@ With --gpus N > 1 and no torchrun environment, bench.py starts its own N ranks (
 the GPU and relays rank 0's JSON line; launched under torchrun it is a rank.
 
 One "step" = one igw_step_walking launch over every env of the rank (one env.step() per env, reward
-and done included, auto-reset of finished episodes inside the launch).  Workload = BASELINE.json
+and done included, auto-reset of finished episodes inside the launch).  Headline workload = BASELINE.json
 configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block targets (rt20, full
 maximal_intersection reward), uniform random actions that are already resident in HBM when the timed
 region starts.  Weak scaling: every rank owns its own 65,536 envs; no data-path collective.
 
 Steady state before the clock: episodes are de-synchronised (every env starts at a random step of its
 episode, then an untimed pre-roll of at least 250 steps; 0.3 s more of it right before the clock, after the
-graph capture, so the GPU is at its working clocks), so any timed window -- also a 20-step
-one -- sees the steady-state fraction of grid-changing steps and about N/250 auto-resets per launch.  The K
-timed launches are 2 eager launches followed by ONE HIP-graph replay of the other K - 2 (captured and
-instantiated before the clock), inside the barrier / synchronize bracket, so a short window is
-kernel-bound, not host-launch-bound (--no-graph times eager launches only).  The whole W + K sequence is
-rehearsed a fixed 3 times, untimed, before the measured (always the last) pass: the first passes through the
-host launch paths cost tens of microseconds more than later ones (--rehearsals 0 shows it, every pass is
-reported in config.rehearsal_ms_per_step; tools/window_variants.py measures the launch paths).
+graph capture, so the GPU is at its working clocks), so any timed window -- also a 20-step one -- sees the
+steady-state fraction of grid-changing steps and about N/250 auto-resets per launch.
+
+A WINDOW is the contract's measurement: W untimed warm-up steps, then the clock around EXACTLY K steps,
+bracketed by a barrier + torch.cuda.synchronize() on both sides; the K timed launches are 2 eager launches
+followed by ONE HIP-graph replay of the other K - 2 (captured and instantiated before the clock; --no-graph
+times eager launches only), so a short window is kernel-bound, not host-launch-bound.  The run makes
+--rehearsals untimed-in-spirit passes first (host code paths warm; reported) and then --windows complete measured
+windows; before EVERY pass the W + K action buffers are refilled on the device with fresh random actions (same
+buffers, so the captured graph stays valid; untimed), so no pass replays an action it has seen.  `value` is the
+MEDIAN window (max over ranks per window); every window is listed in config.windows_ms_per_step.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
-  roofline     -- HBM roofline of the dominant kernel from ALGORITHMIC bytes per env-step
-                  (1274 + 1106 * p bytes, p = measured fraction of env-steps
-                  whose block count changed) over the kernel's average duration (HIP events on the
-                  launch stream); `traffic` / `hbm_measured_gbs` = PMC bytes of the committed profile;
-  issue        -- the instruction-issue side (the real limiter): VALU instructions per
-                  env-step and per wave from the committed SQ counter profile, waves per SIMD;
-  cpu_baseline -- the CPU oracle (plain-C port of the reference algorithm) timed on the host cores on
-                  a bounded sample of the same workload (N = 1 only).
+  roofline     -- the dominant kernel against the HBM roofline: `achieved` / `frac` from the ALGORITHMIC bytes per
+                  env-step of SURVEY.md section 8d (1274 + 1106 * p: the int8 grid streamed every step) over the
+                  kernel's average duration measured in this run (HIP events on the launch stream), and next to it
+                  what THIS design has to move (`design_bytes_per_env_step`: the 192-byte occupancy bitmap instead of
+                  the grid, ...) as `frac_design`; `traffic` = PMC bytes of the committed profile.  Fields that come
+                  from a committed profile instead of this run are listed in `from_profile`;
+  issue        -- the instruction-issue side (the real limiter): VALU instructions per wave from
+                  the committed SQ counter profile over THIS run's kernel time -> VALU issue utilisation;
+  cpu_baseline -- the CPU oracle (plain-C port of the reference algorithm) timed on the host cores on bounded
+                  samples: the headline workload on all usable cores and on one, BASELINE configs[0] (1 env,
+                  DUMMY_TASK-equivalent, 1,000 random steps, 1 core) and configs[3] (flying) (N = 1 only);
+  config.flying / config.cdm -- secondary measurements of the same window machinery in the default single-GPU run:
+                  BASELINE configs[3] (flying action space) and the real IGLU targets with partial starting grids.
 """
 import argparse
 import ctypes
 import json
 import os
 import socket
+import statistics
 import subprocess
 import sys
 import time
@@ -50,6 +59,8 @@ ENVS_PER_GPU = 65536
 MAX_STEPS = 250
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 BYTES_BASE, BYTES_CHANGED = 1274, 1106
+GPU_CLOCK_GHZ = 2.4
+CDM_GOALS = os.path.join(ROOT, 'tests', 'golden', 'cdm_goals.npz')
 
 
 def parse_args(argv=None):
@@ -60,16 +71,20 @@ def parse_args(argv=None):
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--lanes-per-env', type=int, default=0)
     ap.add_argument('--seed', type=int, default=2024)
+    ap.add_argument('--windows', type=int, default=7, help='complete measured windows; value = their median')
+    ap.add_argument('--rehearsals', type=int, default=3,
+                    help='passes through the whole W + K sequence before the measured windows (reported, not counted)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--no-async', action='store_true', help='skip the secondary two-sub-batch measurement')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the flying / cdm secondary windows of the default run')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of one HIP-graph replay')
-    ap.add_argument('--rehearsals', type=int, default=3,
-                    help='untimed passes through the whole W + K sequence before the measured one (reported)')
     ap.add_argument('--lockstep', action='store_true',
                     help='skip the episode de-synchronisation (round-1 behaviour: all envs at the same episode step)')
     ap.add_argument('--mode', choices=['walking', 'flying'], default='walking',
                     help='walking = BASELINE configs[2] (headline); flying = configs[3]')
+    ap.add_argument('--workload', choices=['rt20', 'cdm'], default='rt20',
+                    help='rt20 = random 20-block targets, empty start (BASELINE); cdm = IGLU CDM structures with partial starting grids')
     ap.add_argument('--debug-flags', type=int, default=0,
                     help='IGW_DIAG=1 only: timing-only ablation switches of the diagnostic library (results invalid)')
     ap.add_argument('--dry-run', action='store_true',
@@ -124,39 +139,95 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
+def cgroup_cpu_quota():
+    """CPUs this process may use according to its cgroup's CFS quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), or
+    None when there is no quota.  os.sched_getaffinity does not see such a limit."""
+    try:
+        with open('/proc/self/cgroup') as f:
+            rel = [l.strip().split(':', 2)[2] for l in f if l.startswith('0::')]
+        paths = ['/sys/fs/cgroup' + (rel[0] if rel else '') + '/cpu.max', '/sys/fs/cgroup/cpu.max']
+        for p in paths:
+            if os.path.exists(p):
+                q, period = open(p).read().split()[:2]
+                if q != 'max':
+                    return float(q) / float(period)
+                break
+    except Exception:
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        period = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            return q / period
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(seed):
-    """Oracle (plain-C port of the reference algorithm) on the host cores: a bounded sample of the same
-    workload (rt20 targets, counter-RNG uniform actions, resets included), sized for ~10 s of wall time."""
+    """Oracle (plain-C port of the reference algorithm) on the host cores, bounded samples (about 25 s in all):
+    the headline workload (rt20 targets, counter-RNG uniform actions, resets included) on every usable core and on
+    one; BASELINE configs[3] (flying) likewise; BASELINE configs[0] (1 env, DUMMY_TASK-equivalent, size_reward=True,
+    1,000 random steps) on one core."""
+    import numpy as np
     from gridworld_amd import workloads
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
-    kw = dict(size_reward=False)
-    n = int(min(16384, max(256, 64 * cores)))
-    tg = workloads.rt20(n, seed).numpy()
-    b = O.OracleBatch(n, **kw)
-    b.set_tasks(tg)
-    b.reset()
-    t = time.perf_counter()
-    b.rollout_walking(10, seed, autoreset=True, nthreads=cores)  # calibration (also warms the threads)
-    rate0 = n * 10 / (time.perf_counter() - t)
-    T = int(min(1500, max(250, round(rate0 * 8 / n / 250) * 250)))
-    b.reset()
-    t = time.perf_counter()
-    steps, changed = b.rollout_walking(T, seed, autoreset=True, nthreads=cores)
-    dt = time.perf_counter() - t
-    # one core, smaller sample
-    n1 = max(256, min(1024, n // 8))
-    b1 = O.OracleBatch(n1, **kw)
-    b1.set_tasks(tg[:n1])
-    b1.reset()
-    t = time.perf_counter()
-    s1, _ = b1.rollout_walking(250, seed, autoreset=True, nthreads=1)
-    dt1 = time.perf_counter() - t
-    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'cpu_model': cpu_model(), 'kind': 'port',
+    affinity = len(os.sched_getaffinity(0))
+    quota = cgroup_cpu_quota()
+    # threads actually used: no more than the cgroup lets run at once
+    cores = int(max(1, min(affinity, int(quota + 0.999) if quota else affinity)))
+
+    def timed(batch, fn, T, nthreads):
+        t = time.perf_counter()
+        steps, changed = fn(T, seed, autoreset=True, nthreads=nthreads)
+        dt = time.perf_counter() - t
+        return steps / dt, dt, changed / max(steps, 1)
+
+    def leg(mode, budget_s):
+        kw = dict(size_reward=False) if mode == 'walking' else dict(size_reward=False, action_space='flying')
+        n = int(min(16384, max(256, 64 * cores)))
+        tg = workloads.rt20(n, seed).numpy()
+        b = O.OracleBatch(n, **kw)
+        b.set_tasks(tg)
+        b.reset()
+        fn = b.rollout_walking if mode == 'walking' else b.rollout_flying
+        rate0, _, _ = timed(b, fn, 10, cores)  # calibration (also warms the threads)
+        T = int(min(1500, max(250, round(rate0 * budget_s / n / 250) * 250)))
+        b.reset()
+        rate, dt, p = timed(b, fn, T, cores)
+        n1 = max(128, min(1024, n // 8)) if mode == 'walking' else 256
+        b1 = O.OracleBatch(n1, **kw)
+        b1.set_tasks(tg[:n1])
+        b1.reset()
+        fn1 = b1.rollout_walking if mode == 'walking' else b1.rollout_flying
+        rate1, dt1, _ = timed(b1, fn1, 250, 1)
+        return rate, dt, p, n, T, rate1, dt1, n1
+
+    rate, dt, p, n, T, rate1, dt1, n1 = leg('walking', 8.0)
+    frate, fdt, fp, fn_, fT, frate1, fdt1, fn1 = leg('flying', 6.0)
+    # BASELINE configs[0]: the loop of examples/run_env.py (1 env, DUMMY_TASK-equivalent, size_reward default True)
+    dummy = np.zeros((1, 9, 11, 11), np.int8)
+    dummy[0, 8, 10, 10] = 1
+    b0 = O.OracleBatch(1, size_reward=True)
+    b0.set_tasks(dummy, invariant=False)
+    b0.reset()
+    b0.rollout_walking(1000, seed, autoreset=True, nthreads=1)  # warm
+    b0.reset()
+    rate0, dt0, _ = timed(b0, b0.rollout_walking, 1000, 1)
+    return {'value': rate, 'unit': 'env-steps/s', 'cores': cores, 'cpu_model': cpu_model(), 'kind': 'port',
             'sample': f'{n} envs x {T} steps, rt20 targets, counter-RNG uniform actions, resets included '
                       f'({dt:.1f} s on {cores} threads)',
-            'value_1core': s1 / dt1, 'sample_1core': f'{n1} envs x 250 steps ({dt1:.1f} s)',
-            'p_changed': changed / max(steps, 1)}
+            'affinity_cpus': affinity, 'cgroup_cpu_quota': quota,
+            'effective_cores': round(rate / rate1, 2),   # measured: N-thread rate / 1-thread rate
+            'value_1core': rate1, 'sample_1core': f'{n1} envs x 250 steps ({dt1:.1f} s)',
+            'p_changed': p,
+            'flying': {'value': frate, 'unit': 'env-steps/s', 'cores': cores, 'workload': 'configs[3]',
+                       'sample': f'{fn_} envs x {fT} steps, rt20 targets, uniform movement / camera / inventory / '
+                                 f'placement from the counter RNG, resets included ({fdt:.1f} s on {cores} threads)',
+                       'value_1core': frate1, 'sample_1core': f'{fn1} envs x 250 steps ({fdt1:.1f} s)', 'p_changed': fp},
+            'config0': {'value': rate0, 'unit': 'env-steps/s', 'cores': 1, 'workload': 'configs[0]',
+                        'sample': f'1 env, DUMMY_TASK-equivalent, size_reward=True, 1000 counter-RNG uniform steps '
+                                  f'({dt0 * 1e3:.1f} ms on 1 thread)'}}
 
 
 def load_profile(suffix, flying=False):
@@ -189,10 +260,277 @@ def dry_run(args):
     for _ in range(3):
         nb.wait()
     total, mx = gdist.reduce_window(args.envs_per_gpu * args.steps, 1e-3 * (rank + 1))
+    wins = gdist.reduce_windows([1e-3 * (rank + 1), 2e-3 * (world - rank)])
     ranks = gdist.gather_counts(rank)
     if rank == 0:
         print(json.dumps({'metric': 'dry-run', 'n_gpus': world, 'ranks': ranks, 'total_steps': total,
-                          'max_elapsed': mx, 'steps': args.steps, 'warmup': args.warmup}))
+                          'max_elapsed': mx, 'windows_max': wins, 'steps': args.steps, 'warmup': args.warmup}))
+
+
+class Runner:
+    """One workload on this rank's GPU: env, tasks, the W + K action buffers (refilled in place before every pass),
+    the captured graph and the contract's window."""
+
+    def __init__(self, args, mode, workload, device, rank, world, node_barrier, N=None):
+        import torch
+        from gridworld_amd import VecGridWorld, _lib as L, workloads
+        self.torch, self.L = torch, L
+        self.args, self.mode, self.workload, self.device, self.rank, self.world = args, mode, workload, device, rank, world
+        self.flying = mode == 'flying'
+        self.N = N = int(N or args.envs_per_gpu)
+        self.K, self.W = args.steps, args.warmup
+        self.env_offset = rank * N  # rank-offset RNG streams / task seeds
+        self.node_barrier = node_barrier
+        self.env = env = VecGridWorld(N, device=device, action_space=mode, size_reward=False, max_steps=MAX_STEPS,
+                                      autoreset=True, lanes_per_env=args.lanes_per_env, debug_flags=args.debug_flags,
+                                      env_index_base=self.env_offset)
+        if workload == 'cdm':
+            import numpy as np
+            tg, st = workloads.cdm(N, args.seed + rank, np.load(CDM_GOALS)['dense'])
+            env.set_tasks(tg.to(device), st.to(device))
+        else:
+            env.set_tasks(workloads.rt20(N, seed=args.seed + rank, device=device))
+        env.reset()
+        self.g = g = torch.Generator(device=device)
+        g.manual_seed(args.seed + 7919 * rank + (1 if self.flying else 0))
+        if not args.lockstep:
+            # every env starts at a random step of its episode (GridWorld.step_no, agent record bytes 48..49)
+            sn = torch.randint(0, MAX_STEPS, (N,), generator=g, device=device, dtype=torch.int32)
+            env.agent_buf[:, 48] = (sn & 0xff).to(torch.uint8)
+            env.agent_buf[:, 49] = (sn >> 8).to(torch.uint8)
+        self.pre_rolled = 0
+        self.passes = 0
+        W, K = self.W, self.K
+        if self.flying:
+            self.acts = (torch.empty((W + K, N, 3), device=device), torch.empty((W + K, N, 2), device=device),
+                         torch.empty((W + K, N), device=device, dtype=torch.int32),
+                         torch.empty((W + K, N), device=device, dtype=torch.int32))
+            self.refill()
+            # the timed loop passes pre-computed device pointers: slicing a tensor per step costs more host time
+            # than the launch itself
+            self.ptrs = [tuple(a[t].data_ptr() for a in self.acts) for t in range(W + K)]
+            self._fn = env.lib.igw_step_flying
+        else:
+            chunk = 256
+            self.actions = [torch.empty((min(chunk, W + K - t0), N), dtype=torch.int32, device=device)
+                            for t0 in range(0, W + K, chunk)]
+            self.refill()
+            self.ptrs = [self.actions[t // chunk][t % chunk].data_ptr() for t in range(W + K)]
+            self._fn = env.lib.igw_step_walking
+        self._ctx = env.ctx
+        if not args.lockstep:
+            self.busy(0.0, MAX_STEPS)  # at least one episode length
+        self.graph, self.head, self.timed_as = None, K, 'eager launches'
+        if not args.no_graph and K > 2:
+            self._capture()
+        self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.cur_h = env._stream()
+
+    # -- actions ----------------------------------------------------------------------------------------------
+    def refill(self):
+        """Fresh random actions into the SAME W + K device buffers (so a captured graph stays valid); untimed."""
+        torch, env = self.torch, self.env
+        self.passes += 1
+        if self.flying:
+            mv, cam, inv, plc = self.acts
+            mv.uniform_(-1, 1, generator=self.g)        # movement ~ U(-1, 1)^3
+            cam.uniform_(-5, 5, generator=self.g)       # camera ~ U(-5, 5)^2
+            inv.random_(0, 7, generator=self.g)
+            plc.random_(0, 3, generator=self.g)
+        else:
+            t0 = self.passes * (self.W + self.K)
+            for a in self.actions:
+                self.L.check(env.lib.igw_fill_actions_walking(env.ctx, a.data_ptr(), a.shape[0], t0, self.args.seed,
+                                                              self.env_offset, env._stream()), 'igw_fill_actions_walking')
+                t0 += a.shape[0]
+
+    def step(self, t, stream):
+        p = self.ptrs[t]
+        rc = self._fn(self._ctx, *p, stream) if self.flying else self._fn(self._ctx, p, stream)
+        if rc:
+            self.L.check(rc, 'igw_step')
+
+    def busy(self, seconds, min_steps):
+        """Untimed stepping with FRESH random actions: the pre-roll to the steady state / the clock ramp."""
+        torch, env = self.torch, self.env
+        t_ramp, n_pre = time.perf_counter(), 0
+        while n_pre < min_steps or time.perf_counter() - t_ramp < seconds:
+            if self.flying:
+                self.refill()
+                for t in range(self.W + self.K):
+                    self.step(t, env._stream())
+                n_pre += self.W + self.K
+            else:  # fused rollout with in-kernel random actions
+                env.rollout(MAX_STEPS, seed=self.args.seed + 17 + self.pre_rolled, t0=self.pre_rolled, env_offset=self.env_offset)
+                n_pre += MAX_STEPS
+                self.pre_rolled += MAX_STEPS
+            torch.cuda.synchronize(self.device)
+
+    # -- the timed launches as a short eager head + ONE HIP graph for the rest --------------------------------
+    def _capture(self):
+        """Capture records launches without running them (the entry points never synchronise or allocate) and
+        instantiation happens here, before the warm-up and the clock.  The eager head starts the GPU within a few
+        microseconds of the clock; the graph is launched while those kernels run, so its launch latency (10-16 us)
+        is off the critical path.  With other ranks alive (an RCCL watchdog thread may touch the runtime) the capture
+        is thread-local; if capture or instantiation fails the window is timed as eager launches, in this process."""
+        torch, W, K = self.torch, self.W, self.K
+        head = 2
+        try:
+            graph = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=self.device)
+            cap.wait_stream(torch.cuda.current_stream(self.device))
+            mode = 'thread_local' if self.world > 1 else 'global'
+            with torch.cuda.graph(graph, stream=cap, capture_error_mode=mode):
+                cap_h = ctypes.c_void_p(cap.cuda_stream)
+                for t in range(W + head, W + K):
+                    self.step(t, cap_h)
+            torch.cuda.current_stream(self.device).wait_stream(cap)
+            graph.replay()  # part of the setup: the first launch of a graph also uploads it
+            torch.cuda.synchronize(self.device)
+            self.graph, self.head = graph, head
+            self.timed_as = f'{head} eager launches + one HIP-graph replay of the other {K - head}'
+        except Exception as e:  # noqa: BLE001 -- any capture / instantiate failure: eager launches instead
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:  # noqa: BLE001
+                pass
+            self.graph, self.head = None, K
+            self.timed_as = 'eager launches (graph capture failed: %s)' % (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
+
+    def window(self):
+        """Refill (untimed), W untimed warm-up steps, then the clock around exactly K steps.  Returns (wall seconds,
+        counters before the clock as a device tensor, kernel ms per launch from HIP events, host timeline)."""
+        torch, env, W, K, cur_h = self.torch, self.env, self.W, self.K, self.cur_h
+        ev0, ev1 = self.ev0, self.ev1
+        self.refill()
+        # warm-up right before the clock; the counters are snapshotted on the device, not read, so nothing idles
+        # the GPU between warm-up and clock
+        for t in range(W):
+            self.step(t, cur_h)
+        before = env.stats_buf.sum(0)
+        ev0.record()   # torch creates the HIP events lazily at their first record(): not inside the clock
+        ev1.record()
+        ev1.query()
+        self.node_barrier.wait()
+        torch.cuda.synchronize(self.device)
+        if K == 1:
+            ev0.record()
+        t_start = time.perf_counter()
+        self.step(W, cur_h)
+        # The HIP-event window (kernel duration for the roofline) opens behind the first timed launch and spans the
+        # other K - 1: an event recorded on the idle stream would be processed at once and the window would then
+        # contain the launch latency of the first kernel, not only kernels.  The GPU is busy with that first launch
+        # while the host records, so the wall clock does not see it.
+        if K > 1:
+            ev0.record()
+        for t in range(W + 1, W + self.head):
+            self.step(t, cur_h)
+        t_b = time.perf_counter()
+        if self.graph is not None:
+            self.graph.replay()
+        t_c = time.perf_counter()
+        ev1.record()
+        t_d = time.perf_counter()
+        while not ev1.query():  # spin: a blocking synchronize sleeps on an interrupt and wakes tens of us late
+            pass
+        t_e = time.perf_counter()
+        torch.cuda.synchronize(self.device)
+        t_f = time.perf_counter()
+        self.node_barrier.wait()
+        t_end = time.perf_counter()
+        kernel_ms = ev0.elapsed_time(ev1) / max(K - 1, 1)  # the event window spans the last K - 1 timed launches
+        return t_end - t_start, before, kernel_ms, (t_b - t_start, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e, t_end - t_f)
+
+    def measure(self, windows, rehearsals):
+        """`rehearsals` passes that are reported but not counted, then `windows` measured ones.  The first passes
+        through the host code paths (Python bytecode, ctypes thunks, the HIP runtime's launch and graph-launch paths)
+        cost 30-80 us more than later ones -- 10-20 % of a 20-step window and nothing to do with the step kernel.
+        Right before them 0.3 s of untimed stepping: task upload, graph capture and instantiation leave the GPU idle
+        for tens of milliseconds and its clocks drop."""
+        from gridworld_amd import dist as gdist
+        L, env, N, K = self.L, self.env, self.N, self.K
+        if not self.args.lockstep:
+            self.busy(0.3, 0)
+        rehearsal_ms = [round(1e3 * self.window()[0] / K, 5) for _ in range(rehearsals)]
+        walls, kernels, ps, resets, cells = [], [], [], [], []
+        for _ in range(max(1, windows)):
+            el, st0_dev, kms, host_tl = self.window()
+            s0, s1 = st0_dev.cpu(), env.stats_buf.sum(0).cpu()
+            walls.append(el)
+            kernels.append(kms)
+            ps.append(float(s1[L.STAT_CHANGED] - s0[L.STAT_CHANGED]) / (N * K))
+            cells.append(float(s1[L.STAT_RESCANS] - s0[L.STAT_RESCANS]) / (N * K))
+            resets.append(int(s1[L.STAT_RESETS] - s0[L.STAT_RESETS]))
+            if os.environ.get('IGW_BENCH_TRACE'):
+                print('host us: head launches %.1f | graph launch %.1f | ev1.record %.1f | spin %.1f | synchronize %.1f | '
+                      'barrier %.1f | total %.1f | kernel %.2f us' % (tuple(1e6 * x for x in host_tl) + (1e6 * el, 1e3 * kms)),
+                      file=sys.stderr)
+        # per window the MAX over ranks (one collective for all windows), then the median window
+        walls_max = gdist.reduce_windows(walls, self.device)
+        med = statistics.median(walls_max)
+        i_med = min(range(len(walls_max)), key=lambda i: abs(walls_max[i] - med))
+        return {'elapsed': med, 'windows_ms_per_step': [round(1e3 * w / K, 5) for w in walls_max],
+                'windows_kernel_us': [round(1e3 * k, 3) for k in kernels],
+                'window_spread': (max(walls_max) - min(walls_max)) / med,
+                'rehearsal_ms_per_step': rehearsal_ms,
+                'kernel_ms': statistics.median(kernels), 'p_changed': ps[i_med], 'p_cell_changed': cells[i_med],
+                'resets_in_window': resets[i_med]}
+
+
+def roofline_of(r, m, lanes, has_start_frac=0.0):
+    """The roofline object of a measured workload (see the module docstring)."""
+    N, flying = r.N, r.flying
+    kernel_ms, p, pc = m['kernel_ms'], m['p_changed'], m['p_cell_changed']
+    resets_per_step = m['resets_in_window'] / float(N * r.K)
+    bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4
+    achieved = N * bytes_per_step / (kernel_ms * 1e-3) / 1e9
+    # What this design has to move per env-step (DESIGN.md section 3/4): occupancy bitmap 192 r, agent record 64 r +
+    # 64 w, action 4 (28 flying), task index 4, outputs 53 w (agentPos 20, inventory 24, compass / reward 4 + 4, done
+    # 1); per changed cell: histogram row 1024 r, target level 128 + start byte 4 + boxes 16 r, about four 16-byte
+    # histogram pieces + 1 grid byte + 1 bitmap word w, the break's colour byte r; per auto-reset: starting grid row
+    # 1104 r (only with a starting grid), grid row 1104 w, bitmap 192 w (+ 192 r), histogram row 1024 w, metadata
+    # 128 r, agent record 64 w, observations 49 w.
+    base = 192 + 64 + 64 + (28 if flying else 4) + 4 + 53
+    per_cell = 1024 + 128 + 4 + 16 + 64 + 1 + 4 + 1
+    per_reset = 1104 + 192 + 1024 + 128 + 64 + 49 + has_start_frac * (1104 + 192)
+    design = base + pc * per_cell + resets_per_step * per_reset
+    achieved_design = N * design / (kernel_ms * 1e-3) / 1e9
+    traffic = load_profile('traffic.json', flying)
+    issue = load_profile('issue.json', flying)
+    hbm_bytes = None if traffic is None else traffic.get('hbm_bytes_per_launch')
+    prof_envs = None if traffic is None else traffic.get('envs', ENVS_PER_GPU)
+    if hbm_bytes is not None and prof_envs and prof_envs != N:
+        hbm_bytes = hbm_bytes * N / prof_envs   # the committed profile is of the 65,536-env launch
+    roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': hbm_bytes,
+            'kernel': 'igw::step_kernel<%d, %d, false>' % (lanes, 1 if flying else 0), 'kernel_avg_ms': kernel_ms,
+            'algorithmic_bytes_per_env_step': bytes_per_step,
+            'algorithmic_bytes_per_launch': N * bytes_per_step,
+            # the same kernel time against what this design must move: the kernel is NOT HBM-bound
+            'design_bytes_per_env_step': design, 'achieved_design': achieved_design,
+            'frac_design': achieved_design / HBM_PEAK_GBS,
+            'hbm_measured_gbs': None if hbm_bytes is None else hbm_bytes / (kernel_ms * 1e-3) / 1e9,
+            'hbm_measured_frac': None if hbm_bytes is None else hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'limiter': 'issue',   # see the `issue` object: instruction issue of the waves sharing a SIMD
+            'measured_in_this_run': ['achieved', 'frac', 'kernel_avg_ms', 'algorithmic_bytes_per_env_step',
+                                     'design_bytes_per_env_step', 'achieved_design', 'frac_design'],
+            'from_profile': {'fields': ['traffic', 'hbm_measured_gbs (bytes of the profile / this run\'s kernel time)',
+                                        'hbm_measured_frac'],
+                             'source': None if traffic is None else traffic.get('_file')}}
+    iss = None
+    if issue is not None:
+        valu = issue.get('valu_insts_per_wave')
+        waves_per_simd = (N * lanes / 64.0) / 1024.0   # 256 CUs x 4 SIMDs
+        iss = {'bound': 'issue', 'source': issue.get('_file'),
+               'from_profile': {k: issue.get(k) for k in ('valu_insts_per_wave', 'salu_insts_per_wave', 'lds_insts_per_wave',
+                                                          'frac_wave_time_parked_on_waitcnt', 'frac_wave_time_issue_stalled',
+                                                          'frac_wave_time_issuing', 'kernel_avg_ns', 'dispatches_averaged')},
+               'waves_per_simd': waves_per_simd,
+               # one VALU instruction occupies its SIMD for 4 cycles: share of THIS run's kernel time the SIMDs spend
+               # issuing VALU instructions (instruction count of the profile, kernel time of this run)
+               'valu_issue_util_per_simd': None if not valu else valu * waves_per_simd * 4.0 / (kernel_ms * 1e-3 * GPU_CLOCK_GHZ * 1e9),
+               'valu_insts_per_env_step': None if not valu else valu * lanes / 64.0}
+    return roof, iss
 
 
 def main():
@@ -203,7 +541,7 @@ def main():
         return dry_run(args)
 
     import torch
-    from gridworld_amd import VecGridWorld, dist as gdist, workloads
+    from gridworld_amd import _lib as L, dist as gdist
     rank, local_rank, world = gdist.init()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
@@ -213,211 +551,55 @@ def main():
     device = torch.device('cuda', 0 if os.environ.get('IGW_SHARE_GPU') else local_rank)
     torch.cuda.set_device(device)
     N, K, W = args.envs_per_gpu, args.steps, args.warmup
-    env_offset = rank * N  # rank-offset RNG streams / task seeds
-
     flying = args.mode == 'flying'
-    env = VecGridWorld(N, device=device, action_space=args.mode, size_reward=False, max_steps=MAX_STEPS,
-                       autoreset=True, lanes_per_env=args.lanes_per_env, debug_flags=args.debug_flags)
-    env.set_tasks(workloads.rt20(N, seed=args.seed + rank, device=device))
-    env.reset()
-    g = torch.Generator(device=device)
-    g.manual_seed(args.seed + 7919 * rank)
-    if not args.lockstep:
-        # every env starts at a random step of its episode (GridWorld.step_no, agent record bytes 48..49)
-        sn = torch.randint(0, MAX_STEPS, (N,), generator=g, device=device, dtype=torch.int32)
-        env.agent_buf[:, 48] = (sn & 0xff).to(torch.uint8)
-        env.agent_buf[:, 49] = (sn >> 8).to(torch.uint8)
-
-    # actions for pre-roll, warmup and the timed steps are generated on the device before the clock starts
-    if flying:
-        fly_fused = not args.no_fused
-        args.no_fused = True  # the fused rollout with in-kernel random actions is walking-only
-        from gridworld_amd import _lib as L
-
-        def fly_actions(n_steps):
-            mv = torch.rand((n_steps, N, 3), generator=g, device=device) * 2 - 1      # movement ~ U(-1, 1)^3
-            cam = torch.rand((n_steps, N, 2), generator=g, device=device) * 10 - 5    # camera ~ U(-5, 5)^2
-            inv = torch.randint(0, 7, (n_steps, N), generator=g, device=device, dtype=torch.int32)
-            plc = torch.randint(0, 3, (n_steps, N), generator=g, device=device, dtype=torch.int32)
-            return mv, cam, inv, plc
-
-        def fly_step(a, t):
-            L.check(env.lib.igw_step_flying(env.ctx, a[0][t].data_ptr(), a[1][t].data_ptr(), a[2][t].data_ptr(),
-                                            a[3][t].data_ptr(), env._stream()), 'igw_step_flying')
-        def busy(seconds, min_steps):
-            """Untimed stepping with FRESH random actions: the pre-roll to the steady state / the clock ramp."""
-            t_ramp, n_pre = time.perf_counter(), 0
-            while n_pre < min_steps or time.perf_counter() - t_ramp < seconds:
-                pre = fly_actions(50)
-                for t in range(50):
-                    fly_step(pre, t)
-                torch.cuda.synchronize(device)
-                n_pre += 50
-        if not args.lockstep:
-            busy(0.0, MAX_STEPS)  # at least one episode length
-        acts = fly_actions(W + K)
-        # the timed loop passes pre-computed device pointers: slicing a tensor per step costs more host time
-        # than the launch itself
-        fptrs = [tuple(a[t].data_ptr() for a in acts) for t in range(W + K)]
-        fly_fn, ctx_h = env.lib.igw_step_flying, env.ctx
-
-        def step(t, stream):
-            p = fptrs[t]
-            rc = fly_fn(ctx_h, p[0], p[1], p[2], p[3], stream)
-            if rc:
-                L.check(rc, 'igw_step_flying')
-    else:
-        pre_rolled = [0]
-
-        def busy(seconds, min_steps):
-            """Untimed stepping with fresh in-kernel random actions (fused rollout): the pre-roll to the steady
-            state / the clock ramp."""
-            t_ramp, n_pre = time.perf_counter(), 0
-            while n_pre < min_steps or time.perf_counter() - t_ramp < seconds:
-                env.rollout(MAX_STEPS, seed=args.seed + 17 + pre_rolled[0], t0=pre_rolled[0], env_offset=env_offset)
-                torch.cuda.synchronize(device)
-                n_pre += MAX_STEPS
-                pre_rolled[0] += MAX_STEPS
-        if not args.lockstep:
-            busy(0.0, MAX_STEPS)  # at least one episode length
-        chunk = 256
-        actions = [env.fill_actions(min(chunk, W + K - t0), seed=args.seed, t0=t0, env_offset=env_offset)
-                   for t0 in range(0, W + K, chunk)]
-
-        # the timed loop passes pre-computed device pointers: slicing a tensor per step costs more host time
-        # than the launch itself (tools/window_variants.py: 3.5 us per launch this way, 9-17 us through the
-        # tensor-slicing wrapper)
-        wptrs = [actions[t // chunk][t % chunk].data_ptr() for t in range(W + K)]
-        walk_fn, ctx_h = env.lib.igw_step_walking, env.ctx
-        from gridworld_amd import _lib as L
-
-        def step(t, stream):
-            rc = walk_fn(ctx_h, wptrs[t], stream)
-            if rc:
-                L.check(rc, 'igw_step_walking')
-
-    # The timed launches as a short eager head + ONE HIP graph for the rest.  Capture records launches without
-    # running them (the entry points never synchronise or allocate) and instantiation happens here, before the
-    # warm-up and the clock.  The eager head starts the GPU within a few microseconds of the clock; the graph is
-    # launched while those kernels run, so its launch latency (10-16 us) is off the critical path.
-    graph, head = None, K
-    if not args.no_graph and K > 2:
-        head = 2
-        graph = torch.cuda.CUDAGraph()
-        cap = torch.cuda.Stream(device=device)
-        cap.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.graph(graph, stream=cap):
-            cap_h = ctypes.c_void_p(cap.cuda_stream)
-            for t in range(W + head, W + K):
-                step(t, cap_h)
-        torch.cuda.current_stream(device).wait_stream(cap)
-        graph.replay()  # part of the setup: the first launch of a graph also uploads it
-        torch.cuda.synchronize(device)
-    cur_h = env._stream()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # the barrier of the timing bracket: ranks of one node meet in shared memory (microseconds; an RCCL barrier
     # costs 50-100 us, a quarter of a 20-step window)
     node_barrier = gdist.NodeBarrier()
 
-    def window():
-        """W untimed warm-up steps, then the clock around exactly K steps.  Returns (wall seconds, counters before
-        the clock as a device tensor, host timeline)."""
-        # warm-up right before the clock; the counters are snapshotted on the device, not read, so nothing idles
-        # the GPU between warm-up and clock
-        for t in range(W):
-            step(t, cur_h)
-        before = env.stats_buf.sum(0)
-        ev0.record()   # torch creates the HIP events lazily at their first record(): not inside the clock
-        ev1.record()
-        ev1.query()
-        node_barrier.wait()
-        torch.cuda.synchronize(device)
-        if K == 1:
-            ev0.record()
-        t_start = time.perf_counter()
-        step(W, cur_h)
-        # The HIP-event window (kernel duration for the roofline) opens behind the first timed launch and spans the
-        # other K - 1: an event recorded on the idle stream would be processed at once and the window would then
-        # contain the launch latency of the first kernel, not only kernels.  The GPU is busy with that first launch
-        # while the host records, so the wall clock does not see it.
-        if K > 1:
-            ev0.record()
-        for t in range(W + 1, W + head):
-            step(t, cur_h)
-        t_b = time.perf_counter()
-        if graph is not None:
-            graph.replay()
-        t_c = time.perf_counter()
-        ev1.record()
-        t_d = time.perf_counter()
-        while not ev1.query():  # spin: a blocking synchronize sleeps on an interrupt and wakes tens of us late
-            pass
-        t_e = time.perf_counter()
-        torch.cuda.synchronize(device)
-        t_f = time.perf_counter()
-        node_barrier.wait()
-        t_end = time.perf_counter()
-        return t_end - t_start, before, (t_b - t_start, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e, t_end - t_f)
-
-    # A fixed number of untimed rehearsals of the whole sequence first: the first passes through these host code
-    # paths (Python bytecode, ctypes thunks, the HIP runtime's launch and graph-launch paths) cost 30-80 us more
-    # than later ones, which is 10-20 % of a 20-step window and nothing to do with the step kernel.  A rehearsal
-    # steps the envs like any other warm-up step; the measured pass is always the LAST one, a complete window of
-    # its own, and the rehearsals' ms/step are reported next to it (config.rehearsal_ms_per_step).
-    # ... and, right before them, 0.3 s of untimed stepping: task upload, graph capture and instantiation leave the
-    # GPU idle for tens of milliseconds and its clocks drop; a 20-step window (0.3 ms) would otherwise be measured
-    # on the ramp (16.3 us per launch instead of 15.3)
-    if not args.lockstep:
-        busy(0.3, 0)
-    rehearsal_ms = [round(1e3 * window()[0] / K, 5) for _ in range(args.rehearsals)]
-    elapsed, st0_dev, host_tl = window()
-    if os.environ.get('IGW_BENCH_TRACE'):
-        print('host us: head launches %.1f | graph launch %.1f | ev1.record %.1f | spin %.1f | synchronize %.1f | '
-              'barrier %.1f | total %.1f' % (tuple(1e6 * x for x in host_tl) + (1e6 * elapsed,)), file=sys.stderr)
-    from gridworld_amd import _lib as _L
-    s0 = st0_dev.cpu()
-    st0 = {'changed': int(s0[_L.STAT_CHANGED]), 'resets': int(s0[_L.STAT_RESETS])}
-    st1 = env.stats()
-    kernel_ms = ev0.elapsed_time(ev1) / max(K - 1, 1)  # the event window spans the last K - 1 timed launches
-    total_steps, max_elapsed = gdist.reduce_window(N * K, elapsed, device)
-    n_ranks = len(gdist.gather_counts(rank, device))
+    r = Runner(args, args.mode, args.workload, device, rank, world, node_barrier)
+    env = r.env
+    m = r.measure(args.windows, args.rehearsals)
+    total_steps = N * K * world
+    max_elapsed = m['elapsed']
+    ranks_seen, gather_via = gdist.gather_counts_rccl(rank, device)   # the one RCCL collective: per-rank step counts
+    n_ranks = len(ranks_seen)
 
     # secondary: fused T-step rollout (state resident in LDS/registers, in-kernel RNG)
     fused = fused_rec = None
-    if not args.no_fused:
+    if not args.no_fused and not flying:
         Tf = 250
-        env.rollout(Tf, seed=args.seed + 1, t0=0, env_offset=env_offset)  # warm
+        env.rollout(Tf, seed=args.seed + 1, t0=0, env_offset=r.env_offset)  # warm
         torch.cuda.synchronize(device)
-        gdist.barrier(device)
+        gdist.barrier()
         t0 = time.perf_counter()
-        env.rollout(Tf, seed=args.seed + 2, t0=0, env_offset=env_offset)
+        env.rollout(Tf, seed=args.seed + 2, t0=0, env_offset=r.env_offset)
         torch.cuda.synchronize(device)
-        gdist.barrier(device)
-        f_steps, f_el = gdist.reduce_window(N * Tf, time.perf_counter() - t0, device)
+        gdist.barrier()
+        f_steps, f_el = gdist.reduce_window(N * Tf, time.perf_counter() - t0)
         fused = f_steps / f_el
         # the same fused loop over RECORDED actions (igw_rollout_walking_actions): the first chunk of the timed actions
-        Tr = actions[0].shape[0]
-        env.rollout_actions(actions[0])  # warm
+        Tr = r.actions[0].shape[0]
+        env.rollout_actions(r.actions[0])  # warm
         torch.cuda.synchronize(device)
-        gdist.barrier(device)
+        gdist.barrier()
         t0 = time.perf_counter()
-        env.rollout_actions(actions[0])
+        env.rollout_actions(r.actions[0])
         torch.cuda.synchronize(device)
-        gdist.barrier(device)
-        r_steps, r_el = gdist.reduce_window(N * Tr, time.perf_counter() - t0, device)
+        gdist.barrier()
+        r_steps, r_el = gdist.reduce_window(N * Tr, time.perf_counter() - t0)
         fused_rec = r_steps / r_el
 
-    if flying and fly_fused:   # the fused loop over the recorded flying actions (igw_rollout_flying_actions)
-        rec = dict(movement=acts[0], camera=acts[1], inventory=acts[2], placement=acts[3])
-        Tr = acts[0].shape[0]
+    if flying and not args.no_fused:   # the fused loop over the recorded flying actions (igw_rollout_flying_actions)
+        rec = dict(movement=r.acts[0], camera=r.acts[1], inventory=r.acts[2], placement=r.acts[3])
+        Tr = r.acts[0].shape[0]
         env.rollout_actions(rec)  # warm
         torch.cuda.synchronize(device)
-        gdist.barrier(device)
+        gdist.barrier()
         t0 = time.perf_counter()
         env.rollout_actions(rec)
         torch.cuda.synchronize(device)
-        gdist.barrier(device)
-        r_steps, r_el = gdist.reduce_window(N * Tr, time.perf_counter() - t0, device)
+        gdist.barrier()
+        r_steps, r_el = gdist.reduce_window(N * Tr, time.perf_counter() - t0)
         fused_rec = r_steps / r_el
 
     # secondary: the same kernel as two independent sub-batches on two HIP streams (VecGridWorld.split, the
@@ -428,33 +610,69 @@ def main():
         subs = env.split(2)
         jobs = [(sb.ctx, ctypes.c_void_p(sb.stream.cuda_stream), 4 * sb.lo) for sb in subs]
         Ka = min(K, W + K)
+        walk_fn = env.lib.igw_step_walking
         torch.cuda.synchronize(device)
         for timed in (False, True):
-            gdist.barrier(device)
+            gdist.barrier()
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             for t in range(Ka):
                 for ctx_s, st_s, off in jobs:
-                    rc = walk_fn(ctx_s, wptrs[t] + off, st_s)
+                    rc = walk_fn(ctx_s, r.ptrs[t] + off, st_s)
                     if rc:
                         L.check(rc, 'igw_step_walking')
             torch.cuda.synchronize(device)
-            gdist.barrier(device)
+            gdist.barrier()
             a_el = time.perf_counter() - t0
-        a_steps, a_el = gdist.reduce_window(N * Ka, a_el, device)
+        a_steps, a_el = gdist.reduce_window(N * Ka, a_el)
         async2 = a_steps / a_el
         del subs
 
+    lanes = env.cfg.lanes_per_env or auto_lanes(N)
+    roof, iss = roofline_of(r, m, lanes, has_start_frac=0.96 if args.workload == 'cdm' else 0.0)
+    timed_as = r.timed_as
+
+    # secondaries of the default single-GPU run: BASELINE configs[3] (flying) and the real IGLU targets with partial
+    # starting grids, through the same window machinery (fewer windows)
+    secondary = {}
+    if world == 1 and not args.no_secondary and not flying and args.workload == 'rt20' and not args.debug_flags:
+        del r, env
+        torch.cuda.empty_cache()
+        for key, mode, wl in (('flying', 'flying', 'rt20'), ('cdm', 'walking', 'cdm')):
+            r2 = Runner(args, mode, wl, device, rank, world, node_barrier)
+            m2 = r2.measure(max(3, args.windows // 2), 2)
+            roof2, iss2 = roofline_of(r2, m2, lanes, has_start_frac=0.96 if wl == 'cdm' else 0.0)
+            secondary[key] = {
+                'workload': ('configs[3]: 65,536 parallel envs, flying action space (continuous movement / camera Box), '
+                             'random 20-block targets (rt20), uniform random actions, auto-reset at done (max_steps=250)')
+                if key == 'flying' else
+                ('65,536 parallel envs, walking Discrete(18), the 156 IGLU CDM target structures tiled over the batch, '
+                 'each with a random partial starting grid (96 % of the envs; a third with blocks that are not in the '
+                 'target: negative synthetic ids), uniform random actions, auto-reset at done (max_steps=250)'),
+                'value': N * K / m2['elapsed'], 'unit': 'env-steps/s', 'ms_per_step': 1e3 * m2['elapsed'] / K,
+                'windows_ms_per_step': m2['windows_ms_per_step'], 'kernel_us': 1e3 * m2['kernel_ms'],
+                'p_changed': m2['p_changed'], 'p_cell_changed': m2['p_cell_changed'],
+                'resets_in_window': m2['resets_in_window'], 'timed_as': r2.timed_as,
+                'roofline': {k: roof2[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel',
+                                                   'kernel_avg_ms', 'design_bytes_per_env_step', 'frac_design', 'limiter')},
+                'valu_issue_util_per_simd': None if iss2 is None else iss2['valu_issue_util_per_simd']}
+            del r2
+            torch.cuda.empty_cache()
+
     if rank != 0:
         return
-    lanes = env.cfg.lanes_per_env or auto_lanes(N)
-    p = (st1['changed'] - st0['changed']) / float(N * K)
-    resets = st1['resets'] - st0['resets']
-    bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4
-    achieved = N * bytes_per_step / (kernel_ms * 1e-3) / 1e9
-    traffic = load_profile('traffic.json', flying)
-    issue = load_profile('issue.json', flying)
-    hbm_bytes = None if traffic is None else traffic.get('hbm_bytes_per_launch')
+    wl_text = {('walking', 'rt20'): 'configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block '
+                                    'targets (rt20), full maximal_intersection reward, uniform random actions, '
+                                    'auto-reset at done (max_steps=250)',
+               ('flying', 'rt20'): 'configs[3]: 65,536 parallel envs per GPU, flying action space (continuous movement / '
+                                   'camera Box), random 20-block targets (rt20), uniform random actions, auto-reset at '
+                                   'done (max_steps=250)',
+               ('walking', 'cdm'): 'IGLU CDM target structures with random partial starting grids, walking Discrete(18), '
+                                   'uniform random actions, auto-reset at done (max_steps=250)',
+               ('flying', 'cdm'): 'IGLU CDM target structures with random partial starting grids, flying action space, '
+                                  'uniform random actions, auto-reset at done (max_steps=250)'}[(args.mode, args.workload)]
+    if N != ENVS_PER_GPU:
+        wl_text = wl_text.replace('65,536', f'{N:,}')
     out = {
         'metric': 'env-steps/sec (render=False, vector_state) at N parallel envs, 1/2/4/8 GPU',
         'value': total_steps / max_elapsed,
@@ -468,37 +686,32 @@ def main():
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': ('configs[3]: 65,536 parallel envs per GPU, flying action space (continuous movement / '
-                                'camera Box), random 20-block targets (rt20), uniform random actions, auto-reset at '
-                                'done (max_steps=250)') if flying else
-                               ('configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block '
-                                'targets (rt20), full maximal_intersection reward, uniform random actions, '
-                                'auto-reset at done (max_steps=250)'),
+        'config': {'workload': wl_text,
                    'envs_per_gpu': N, 'total_envs': N * n_ranks, 'lanes_per_env': lanes,
                    'launches_per_step': 1,
-                   'timed_as': 'eager launches' if graph is None else f'{head} eager launches + one HIP-graph replay of the other {K - head}',
+                   'timed_as': timed_as,
+                   'value_is': 'median of %d complete windows (W warm-up steps, barrier + synchronize, K timed steps, '
+                               'synchronize + barrier; max over ranks per window)' % len(m['windows_ms_per_step']),
+                   'windows_ms_per_step': m['windows_ms_per_step'], 'window_spread': m['window_spread'],
+                   'windows_kernel_us': m['windows_kernel_us'],
                    'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + pre-roll)',
-                   'setup': 'untimed: task upload, pre-roll of >= 250 steps with fresh random actions (steady state), graph capture + one replay, 0.3 s more of such stepping (clock ramp), %d untimed rehearsals of the W + K sequence (host code paths warm), then the W warm-up steps and the clock' % args.rehearsals,
-                   'rehearsal_ms_per_step': rehearsal_ms,
-                   'resets_in_window': resets, 'p_changed': p,
+                   'setup': 'untimed: task upload, pre-roll of >= 250 steps with fresh random actions (steady state), graph '
+                            'capture + one replay, 0.3 s more of such stepping (clock ramp), %d rehearsal passes (host code '
+                            'paths warm; reported, not counted); before every pass the W + K action buffers are refilled '
+                            'on the device with fresh random actions' % args.rehearsals,
+                   'rehearsal_ms_per_step': m['rehearsal_ms_per_step'],
+                   'resets_in_window': m['resets_in_window'], 'p_changed': m['p_changed'],
+                   'p_cell_changed': m['p_cell_changed'],
+                   'step_count_gather': gather_via,
                    'fused_rollout_env_steps_per_s': fused,
                    'fused_rollout_recorded_actions_env_steps_per_s': fused_rec,
                    'async_2_subbatches_env_steps_per_s': async2},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': hbm_bytes,
-                     'kernel': 'igw::step_kernel<%d, %d, false>' % (lanes, 1 if flying else 0), 'kernel_avg_ms': kernel_ms,
-                     'algorithmic_bytes_per_env_step': bytes_per_step,
-                     'algorithmic_bytes_per_launch': N * bytes_per_step,
-                     # what the memory system really moved (committed PMC profile) over this run's kernel time:
-                     # the kernel is latency / issue bound, not HBM bound -- see `issue` and DESIGN.md section 5
-                     'hbm_measured_gbs': None if hbm_bytes is None else hbm_bytes / (kernel_ms * 1e-3) / 1e9,
-                     'hbm_measured_frac': None if hbm_bytes is None else hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     'traffic_profile': None if traffic is None else traffic.get('_file')},
+        'roofline': roof,
     }
-    if issue is not None:
-        out['issue'] = {k: v for k, v in issue.items() if not k.startswith('_') and k != 'raw'}
-        out['issue']['profile'] = issue.get('_file')
-    if world == 1 and not args.no_cpu_baseline and not flying:
+    out['config'].update(secondary)
+    if iss is not None:
+        out['issue'] = iss
+    if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.seed)
     print(json.dumps(out))
 

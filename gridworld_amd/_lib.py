@@ -22,6 +22,7 @@ STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS, STAT_BAD_POSE, STAT_BAD_ACT
 VERSION = 2
 WALKING_DISCRETE, FLYING, WALKING_DICT = 0, 1, 2
 RESET_KEEP_SIZE = 1
+CAMERA_MAX = 1e6   # IGW_CAMERA_MAX
 
 # every symbol include/igw.h declares (checked by tests/test_abi.py)
 EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',

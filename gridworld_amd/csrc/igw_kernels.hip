@@ -442,6 +442,12 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
     while (e.yaw < 0.0) e.yaw += 360.0;
 }
 
+// A camera delta the step accepts: finite and |v| <= IGW_CAMERA_MAX (the bound of init_pose's yaw / pitch).  The
+// reference wraps yaw with `while yaw > 360: yaw -= 360` (core/world.py:451-456): a finite but huge delta (1e20:
+// yaw - 360 == yaw) would spin that loop forever, on the device a hung kernel.  Anything else runs as a no-op
+// component and is counted (IGW_STAT_BAD_ACTION), like the non-finite values.
+__device__ inline bool camera_ok(double v) { return __builtin_fabs(v) <= IGW_CAMERA_MAX; }  // false for NaN / inf too
+
 // parse_walking_discrete_action (core/world.py:360-394)
 struct WalkAct {
     double s0, s1, dy, cam0, cam1;
@@ -523,6 +529,9 @@ template <int GS>
 struct BlockShared;
 // (the ray march of four-lane groups parks WAVE x 10 keys in the wave's histogram rows, which are idle then)
 static_assert(req_chunk<4>() * (HIST_ROW / 2) >= WAVE * 10, "hit_test scratch");
+// (the RandomTasks generator builds one STRIDE-byte target row in the wave's whole scratch struct, which is idle
+// at the end of a step: resolve_resets is handed &ws[wave], not one of its members)
+static_assert(sizeof(WaveScratch<1>) >= (size_t)STRIDE && alignof(WaveScratch<1>) >= 16, "sample_random_task_wave scratch");
 template <int GS>
 struct BlockShared {
     static constexpr int EPB = BLOCK / GS;  // envs per block
@@ -925,7 +934,7 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
         has_start = !p.rt_enabled && meta->has_start != 0;
     }
     resolve_resets<GS, EXTRA>(G, p, do_reset, env, task, has_start, ep, nullptr,
-                              reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
+                              reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size);
     prio_at<true, 7>(boost);
 #ifdef IGW_DIAG
     {
@@ -1031,8 +1040,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         // offending component as a no-op and count it (IGW_STAT_BAD_ACTION)
         bool bad = false;
         if (hotbar > 6) { hotbar = 0; bad = true; }
-        if (!__builtin_isfinite(c0)) { c0 = 0.0; bad = true; }
-        if (!__builtin_isfinite(c1)) { c1 = 0.0; bad = true; }
+        if (!camera_ok(c0)) { c0 = 0.0; bad = true; }
+        if (!camera_ok(c1)) { c1 = 0.0; bad = true; }
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
         const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
         ch = world_act<GS, MODE_WALK_DICT, true>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
@@ -1046,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         if ((unsigned)inventory > 6u) { inventory = 0; bad = true; }
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            if (!__builtin_isfinite(f[i])) { f[i] = 0.0; bad = true; }
+            if (i < 3 ? !__builtin_isfinite(f[i]) : !camera_ok(f[i])) { f[i] = 0.0; bad = true; }
         }
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
         ch = world_act<GS, MODE_FLY, true>(G, p, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
@@ -1172,7 +1181,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
                 if ((unsigned)inventory > 6u) { inventory = 0; bad = true; }
 #pragma unroll
                 for (int i = 0; i < 5; i++) {
-                    if (!__builtin_isfinite(f[i])) { f[i] = 0.0; bad = true; }
+                    if (i < 3 ? !__builtin_isfinite(f[i]) : !camera_ok(f[i])) { f[i] = 0.0; bad = true; }
                 }
                 if (bad && G.gl == 0) stat_add(p1.stats, IGW_STAT_BAD_ACTION, 1);
                 ch = world_act<GS, MODE_FLY>(G, p1, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
@@ -1232,7 +1241,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
         }
         wave_sync();
         resolve_resets<GS, true>(G, p3, do_reset, env, task, has_start, ep, occ_wave_s,
-                                 reinterpret_cast<int8_t*>(sh.ws[wave].hist[0]), generated_size);
+                                 reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (active && do_reset) {
@@ -1750,6 +1759,7 @@ int igw_step_walking_dict(igw_ctx* ctx, const uint8_t* buttons, const float* cam
 
 int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int64_t env_offset, void* stream) {
     CHECK_CTX("igw_rollout_walking");
+    if (ctx->kp.traj) return fail(IGW_ERR_INVALID, "igw_rollout_walking: the episode log is enabled on this context (the fused loop does not write it)");
     if (ctx->cfg.action_space != IGW_WALKING_DISCRETE) return fail(IGW_ERR_INVALID, "igw_rollout_walking: context was created for another action space");
     if (T < 0) return fail(IGW_ERR_INVALID, "igw_rollout_walking: T < 0");
     if (T == 0) return IGW_OK;
@@ -1763,6 +1773,7 @@ int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int6
 int igw_rollout_walking_actions(igw_ctx* ctx, const int32_t* actions, int64_t T, float* rewards, uint8_t* dones,
                                 void* stream) {
     CHECK_CTX("igw_rollout_walking_actions");
+    if (ctx->kp.traj) return fail(IGW_ERR_INVALID, "igw_rollout_walking_actions: the episode log is enabled on this context (the fused loop does not write it)");
     if (ctx->cfg.action_space != IGW_WALKING_DISCRETE) return fail(IGW_ERR_INVALID, "igw_rollout_walking_actions: context was created for another action space");
     if (T < 0 || (T > 0 && !actions)) return fail(IGW_ERR_INVALID, "igw_rollout_walking_actions: bad argument");
     if (T == 0) return IGW_OK;
@@ -1776,6 +1787,7 @@ int igw_rollout_walking_actions(igw_ctx* ctx, const int32_t* actions, int64_t T,
 int igw_rollout_flying_actions(igw_ctx* ctx, const float* movement, const float* camera, const int32_t* inventory,
                                const int32_t* placement, int64_t T, float* rewards, uint8_t* dones, void* stream) {
     CHECK_CTX("igw_rollout_flying_actions");
+    if (ctx->kp.traj) return fail(IGW_ERR_INVALID, "igw_rollout_flying_actions: the episode log is enabled on this context (the fused loop does not write it)");
     if (ctx->cfg.action_space != IGW_FLYING) return fail(IGW_ERR_INVALID, "igw_rollout_flying_actions: context was created for another action space");
     if (T < 0 || (T > 0 && (!movement || !camera || !inventory || !placement))) return fail(IGW_ERR_INVALID, "igw_rollout_flying_actions: bad argument");
     if (T == 0) return IGW_OK;

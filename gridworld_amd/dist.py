@@ -16,17 +16,27 @@ def env_info():
 
 
 def init(backend=None):
-    """Initialises torch.distributed from the torchrun environment (no-op for world size 1)."""
+    """Initialises torch.distributed from the torchrun environment (no-op for world size 1).
+
+    On GPUs the group is MIXED: gloo for CPU tensors, nccl (= RCCL over xGMI) for CUDA tensors.  The control plane
+    of a run -- rendezvous of the shared-memory barrier, the reduction of the timing windows -- goes over gloo, so a
+    bench line is printed whatever the state of the RCCL stack; the per-rank step counts are gathered over RCCL
+    (gather_counts_rccl), falling back to gloo if that collective raises."""
     rank, local_rank, world = env_info()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = os.environ.get('IGW_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            backend = os.environ.get('IGW_DIST_BACKEND') or ('cpu:gloo,cuda:nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
+        if 'nccl' in backend and not os.environ.get('IGW_SHARE_GPU'):
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, device_id=torch.device('cuda', local_rank))
-        else:
+        try:
             dist.init_process_group(backend)
+        except Exception:  # noqa: BLE001 -- e.g. the nccl half cannot be built: the control plane alone will do
+            if 'nccl' not in backend:
+                raise
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group('gloo')
     return rank, local_rank, world
 
 
@@ -37,19 +47,10 @@ def shard_envs(total_envs, rank, world):
     return lo, hi
 
 
-def _comm_device(device):
-    """Tensors for the control-plane collectives live where the backend can reduce them."""
-    if dist.is_initialized() and dist.get_backend() == 'nccl' and device is not None:
-        return device
-    return torch.device('cpu')
-
-
 def barrier(device=None):
+    """Control-plane barrier (gloo when the group has a CPU backend; `device` is accepted for old callers)."""
     if dist.is_initialized():
-        if device is not None and device.type == 'cuda' and dist.get_backend() == 'nccl':
-            dist.barrier(device_ids=[device.index])
-        else:
-            dist.barrier()
+        dist.barrier()
 
 
 class NodeBarrier:
@@ -91,11 +92,20 @@ class NodeBarrier:
                     raise RuntimeError('NodeBarrier: rank %d timed out waiting for the others' % self.rank)
 
 
+def _cpu_ok():
+    """The group can reduce CPU tensors (gloo present)."""
+    return 'gloo' in str(dist.get_backend()) or 'cpu' in str(dist.get_backend_config())
+
+
+def _ctl_device(device):
+    return torch.device('cpu') if _cpu_ok() or device is None else device
+
+
 def reduce_window(steps, seconds, device=None):
     """(total env-steps over all ranks, max elapsed seconds over ranks)."""
     if not dist.is_initialized():
         return int(steps), float(seconds)
-    dev = _comm_device(device)
+    dev = _ctl_device(device)
     s = torch.tensor([int(steps)], dtype=torch.int64, device=dev)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=dev)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
@@ -103,12 +113,42 @@ def reduce_window(steps, seconds, device=None):
     return int(s.item()), float(t.item())
 
 
+def reduce_windows(seconds, device=None):
+    """Per timing window the MAX elapsed seconds over the ranks: one all-reduce for all windows of a run."""
+    seconds = [float(x) for x in seconds]
+    if not dist.is_initialized():
+        return seconds
+    t = torch.tensor(seconds, dtype=torch.float64, device=_ctl_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.cpu()]
+
+
 def gather_counts(value, device=None):
-    """all_gather of one int64 per rank (e.g. per-rank step counters)."""
+    """all_gather of one int64 per rank (e.g. per-rank step counters) over the control plane."""
     if not dist.is_initialized():
         return [int(value)]
-    dev = _comm_device(device)
-    mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=_ctl_device(device))
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
     return [int(o.item()) for o in out]
+
+
+def gather_counts_rccl(value, device):
+    """The same gather over RCCL (CUDA tensors; xGMI between the GPUs of a node) -- the one place the data plane's
+    fabric is used at all.  Returns (values, how): if the RCCL collective raises (no nccl backend in the group, ranks
+    sharing one GPU, a broken fabric) the gather is repeated over gloo and `how` says so."""
+    if not dist.is_initialized():
+        return [int(value)], 'single process'
+    if device is not None and device.type == 'cuda' and 'nccl' in str(dist.get_backend_config()):
+        try:
+            mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
+            out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(out, mine)
+            torch.cuda.synchronize(device)
+            return [int(o.item()) for o in out], 'rccl all_gather of one int64 per rank'
+        except Exception as e:  # noqa: BLE001
+            why = (str(e).splitlines() or [type(e).__name__])[0][:160]
+            if not _cpu_ok():
+                raise
+            return gather_counts(value), 'gloo (rccl all_gather failed: %s)' % why
+    return gather_counts(value), 'gloo'

@@ -44,6 +44,8 @@ class GridWorld:
         self.initial_position = (0, 0, 0)
         self.initial_rotation = (0, 0)
         self.starting_grid = None
+        self.max_int = 0
+        self.prev_grid_size = 0
         if action_space == 'walking' and discretize:
             self.action_space = spaces.Discrete(18)
         elif action_space == 'walking':  # env.py:60-70
@@ -132,6 +134,10 @@ class GridWorld:
         self._vec.reset(keep_size=keep_size)
         obs = self._obs()
         self._counters = self._read_counters()
+        # GridWorld.max_int (env.py:241): the user task -- full_grid admissibility included -- on the starting grid
+        self.max_int = int(self._vec.task_meta[0, 42:44].cpu().numpy().view(np.int16)[0])
+        self.prev_grid_size = int(np.count_nonzero(obs['grid'])) if self.vector_state else \
+            int(np.count_nonzero(self._vec.grid[0].cpu().numpy()))   # env.py:242
         return obs
 
     def reset(self):

@@ -64,10 +64,22 @@ class Tasks:
 
     @classmethod
     def to_sparse(cls, blocks):
-        """dense -> [(x, y, z, id)] in row-major order of (y, x, z): the inverse of to_dense.  (The reference's
-        array branch, task.py:178-187, unpacks nonzero() -- (y, x, z) index order -- as (x, y, z) and so returns
-        (y_idx - 5, x_idx - 1, z_idx - 5, id), which its own to_dense cannot read back; no reference caller passes
-        an array, Subtasks hands over sparse lists that pass through unchanged.)"""
+        """task.py:177-187, as the reference returns it: a sparse list passes through unchanged (what every
+        reference caller hands over, Subtasks.create_task included); for a dense ARRAY the reference unpacks the
+        nonzero() indices -- (y, x, z) order -- as (x, y, z), so the result is
+        (y_idx - 5, x_idx - 1, z_idx - 5, id) in nonzero() order, which its own to_dense does not read back.
+        Kept bit-for-bit (fixture s10_task_protocol: to_sparse_in / to_sparse_out); `dense_to_sparse` is the
+        inverse of to_dense."""
+        if isinstance(blocks, np.ndarray):
+            idx = blocks.nonzero()
+            return [(int(i0) - BUILD_ZONE_SIZE_X // 2, int(i1) - 1, int(i2) - BUILD_ZONE_SIZE_Z // 2,
+                     blocks[i0, i1, i2]) for i0, i1, i2 in zip(*idx)]
+        return blocks
+
+    @classmethod
+    def dense_to_sparse(cls, blocks):
+        """dense [y+1, x+5, z+5] -> [(x, y, z, id)] in row-major order of (y, x, z): the inverse of to_dense
+        (not part of the reference's surface; see to_sparse)."""
         if isinstance(blocks, np.ndarray):
             ys, xs, zs = blocks.nonzero()
             return [(int(x) - BUILD_ZONE_SIZE_X // 2, int(y) - 1, int(z) - BUILD_ZONE_SIZE_Z // 2,
@@ -375,7 +387,7 @@ class Subtasks(_Delegating):
             chat = chat + '\n' + line if chat else line
         blocks_before = [] if turn_start == -1 else self.structure_seq[turn_start]
         task = Task(chat, target_grid=self.to_dense(self.structure_seq[goal]),
-                    starting_grid=self.to_sparse(np.asarray(self.to_dense(blocks_before))),
+                    starting_grid=self.to_sparse(blocks_before),
                     full_grid=self.full_structure, last_instruction='\n'.join(self.dialog[goal]))
         return task.reset()  # max_int on the starting grid, prev_grid_size (task.py:284-285)
 

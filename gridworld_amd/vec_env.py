@@ -36,7 +36,15 @@ class VecGridWorld:
     def __init__(self, num_envs, device='cuda:0', action_space='walking', select_and_place=True,
                  size_reward=True, max_steps=250, right_placement_scale=1., wrong_placement_scale=0.1,
                  discretize=True, autoreset=False, num_tasks=None, lanes_per_env=0, debug_flags=0, env_index_base=0,
-                 **ignored):
+                 render=False, render_size=(64, 64), target_in_obs=False, vector_state=True, name='', fake=False):
+        """create_env's keyword arguments (gridworld/env.py:333-338) plus the batch's own: num_envs, device,
+        autoreset (reset inside step), num_tasks (rows of the task table, default num_envs), lanes_per_env
+        (0 = automatic), env_index_base (global index of env 0: rank / sub-batch offset), debug_flags (IGW_DIAG
+        build only).  Anything else is a TypeError, as in create_env.  render / render_size / fake / name /
+        target_in_obs / vector_state are accepted for signature compatibility: this is the render=False,
+        vector_state=True path (observations are the state tensors; `targets()` gives the target grids)."""
+        if render and not fake:
+            raise NotImplementedError('the renderer is out of scope of the MI355X step path; pass render=False')
         if not torch.cuda.is_available():
             raise L.IgwError('VecGridWorld needs a HIP device (no CPU fallback)')
         if action_space not in ('walking', 'flying'):
@@ -230,6 +238,21 @@ class VecGridWorld:
         self._mask_keep = m
         return self.obs()
 
+    @staticmethod
+    def _check_camera(cam):
+        """Host-side mirror of the kernels' camera screen (IGW_CAMERA_MAX): camera deltas that arrive as HOST data
+        are checked here and raise; device tensors are not read back (that would synchronise every step) -- the
+        kernels run an offending component as a no-op and count it in stats()['bad_actions']."""
+        if torch.is_tensor(cam):
+            if cam.is_cuda:
+                return
+            c = cam.detach().numpy()
+        else:
+            c = np.asarray(cam)
+        c = c.astype(np.float64, copy=False)
+        if c.size and not (np.isfinite(c).all() and np.abs(c).max() <= L.CAMERA_MAX):
+            raise ValueError(f'camera deltas must be finite with |value| <= {L.CAMERA_MAX:g} degrees')
+
     def step(self, actions):
         """walking: int32 tensor [N]; walking with discretize=False: dict(buttons u8[N,8] = forward, back,
         left, right, jump, attack, use, hotbar -- or those eight keys separately -- and camera f32[N,2]);
@@ -237,6 +260,8 @@ class VecGridWorld:
         Returns (obs, reward, done, info) of tensors living in HBM."""
         self._need_tasks()
         dev = self.device
+        if self.walk_dict or self.flying:
+            self._check_camera(actions['camera'])
         if self.walk_dict:
             if 'buttons' in actions:
                 b = torch.as_tensor(actions['buttons'], device=dev).to(torch.uint8).reshape(self.num_envs, 8).contiguous()
@@ -290,7 +315,10 @@ class VecGridWorld:
         N, dev = self.num_envs, self.device
         if self.walk_dict:
             raise L.IgwError('rollout_actions: Discrete(18) walking and flying only')
+        if self._traj is not None:
+            raise L.IgwError('rollout / rollout_actions do not write the episode log: disable_trajectory_log() first')
         if self.flying:   # dict(movement f32[T,N,3], camera f32[T,N,2], inventory i32[T,N], placement i32[T,N])
+            self._check_camera(actions['camera'])
             mv = torch.as_tensor(actions['movement'], device=dev).to(torch.float32).contiguous()
             cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).contiguous()
             inv = torch.as_tensor(actions['inventory'], device=dev).to(torch.int32).contiguous()

@@ -71,8 +71,12 @@ extern "C" {
 #define IGW_STAT_BAD_POSE 4   /* task rows whose init_pose was rejected (non-finite, |x| or |z| > 10, |y| > 64,
                                * |yaw| or |pitch| > 1e6) and replaced by the default pose */
 #define IGW_STAT_BAD_ACTION 5 /* env-steps whose action was rejected and executed as a no-op component: non-finite
-                               * movement / camera values, inventory / hotbar ids outside 0..6 (the reference
-                               * raises ValueError there, core/world.py:354-355) */
+                               * movement / camera values, camera deltas beyond +-IGW_CAMERA_MAX, inventory /
+                               * hotbar ids outside 0..6 (the reference raises ValueError there,
+                               * core/world.py:354-355) */
+/* largest |camera delta| per step (degrees; same bound as init_pose's yaw / pitch): the reference wraps yaw by
+ * repeated subtraction of 360 (core/world.py:451-456), which never ends for a finite but huge value */
+#define IGW_CAMERA_MAX 1e6
 
 enum igw_status {
     IGW_OK = 0,
@@ -200,7 +204,8 @@ int igw_set_random_tasks(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t m
  * 89-121, minus video): for envs [0, n_logged) every step writes one IGW_TRAJ_BYTES record at
  *   records[env][episode[env] & 1][step_no - 1]     (two episodes of `capacity` steps per env, so a finished
  * episode stays readable while the next one is written; steps beyond capacity are not recorded) and keeps
- *   heads[env][episode[env] & 1] = { task row, steps recorded, episode number, 0 }  (int32 x 4) current.
+ *   heads[env][episode[env] & 1] = { task row, steps recorded, episode number, finished }  (int32 x 4) current;
+ * `finished` is the done flag of the last recorded step (1: the episode in this slot is complete).
  * Record layout (little endian):
  *    0 f32 agentPos[5]   20 f32 reward   24 f32 compass   28 i32 change: -1, or cell | (colour & 0xff) << 16
  *   32 u8 inventory[6]   38 u8 done      39 u8 action space (igw_action_space)
@@ -231,7 +236,8 @@ int igw_rollout_walking(igw_ctx* ctx, int64_t T, uint64_t seed, int64_t t0, int6
  * exactly T calls of igw_step_walking (the context's autoreset setting applies), in one launch and without a
  * barrier between the steps of different envs.  rewards (float [T][N]) / dones (uint8 [T][N]) receive every step's
  * values when not NULL; the per-env outputs of igw_buffers hold the last step's, as after igw_step_walking.
- * <- the loop of examples/run_env.py:18-26 over a recorded action sequence.  Not with the episode log. */
+ * <- the loop of examples/run_env.py:18-26 over a recorded action sequence.  The three igw_rollout_* entry points
+ * do not write the episode log: they return IGW_ERR_INVALID while igw_set_trajectory_log is enabled. */
 int igw_rollout_walking_actions(igw_ctx* ctx, const int32_t* actions, int64_t T, float* rewards, uint8_t* dones,
                                 void* stream);
 /* ... and for the flying action space: movement float [T][N][3], camera float [T][N][2], inventory / placement

@@ -631,7 +631,7 @@ static inline int rng_action18(uint64_t seed, uint64_t env, uint64_t t) {
 }
 
 typedef struct {
-    int kind; /* 0 walking step, 1 flying step, 2 walking rollout, 3 walking Dict step */
+    int kind; /* 0 walking step, 1 flying step, 2 walking rollout, 3 walking Dict step, 4 flying rollout */
     const uint8_t* buttons;
     igo_env** envs;
     int64_t lo, hi;
@@ -653,6 +653,28 @@ static void* job_run(void* arg) {
             for (int64_t t = 0; t < j->T; t++) {
                 int before = e->synth.prev_grid_size;
                 igo_step_walking(e, rng_action18(j->seed, (uint64_t)(j->env_offset + i), (uint64_t)t));
+                j->changed += e->synth.prev_grid_size != before;
+                j->steps++;
+                if (e->done && j->autoreset) igo_reset(e);
+            }
+            continue;
+        }
+        if (j->kind == 4) { /* flying rollout: movement ~ U(-1,1)^3, camera ~ U(-5,5)^2 (float32 values, as the
+                             * action Box is float32), inventory U{0..6}, placement U{0..2} from the counter RNG */
+            for (int64_t t = 0; t < j->T; t++) {
+                uint64_t h = splitmix64(j->seed ^ splitmix64((uint64_t)(j->env_offset + i) * 0x100000001B3ull + (uint64_t)t));
+                double mv[3], cam[2];
+                for (int k = 0; k < 5; k++) {
+                    h = splitmix64(h + (uint64_t)k);
+                    float u = (float)((h >> 40) * (1.0 / 16777216.0)); /* [0, 1) */
+                    if (k < 3) mv[k] = (double)(2.0f * u - 1.0f);
+                    else cam[k - 3] = (double)(10.0f * u - 5.0f);
+                }
+                h = splitmix64(h + 5u);
+                int inventory = (int)(((h >> 32) * 7ull) >> 32);
+                int placement = (int)(((h & 0xffffffffull) * 3ull) >> 32);
+                int before = e->synth.prev_grid_size;
+                igo_step_flying(e, mv, cam, inventory, placement);
                 j->changed += e->synth.prev_grid_size != before;
                 j->steps++;
                 if (e->done && j->autoreset) igo_reset(e);
@@ -730,6 +752,18 @@ int64_t igo_batch_rollout_walking(igo_env** envs, int64_t n, int64_t T, uint64_t
     int64_t steps = 0;
     memset(&j, 0, sizeof(j));
     j.kind = 2; j.envs = envs; j.T = T; j.seed = seed; j.env_offset = env_offset;
+    j.autoreset = autoreset;
+    run_jobs(&j, n, nthreads, &steps, changed_steps);
+    return steps;
+}
+
+int64_t igo_batch_rollout_flying(igo_env** envs, int64_t n, int64_t T, uint64_t seed,
+                                 int64_t env_offset, int autoreset, int nthreads,
+                                 int64_t* changed_steps) {
+    job_t j;
+    int64_t steps = 0;
+    memset(&j, 0, sizeof(j));
+    j.kind = 4; j.envs = envs; j.T = T; j.seed = seed; j.env_offset = env_offset;
     j.autoreset = autoreset;
     run_jobs(&j, n, nthreads, &steps, changed_steps);
     return steps;

@@ -120,6 +120,8 @@ def lib():
         L.igo_batch_rollout_walking.restype = C.c_int64
         L.igo_batch_rollout_walking.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64,
                                                 C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.igo_batch_rollout_flying.restype = C.c_int64
+        L.igo_batch_rollout_flying.argtypes = L.igo_batch_rollout_walking.argtypes
         _lib = L
     return _lib
 
@@ -281,6 +283,12 @@ class OracleBatch:
         changed = np.zeros(1, np.int64)
         steps = lib().igo_batch_rollout_walking(self.handles, self.n, T, seed, env_offset,
                                                 int(autoreset), nthreads, _p(changed))
+        return int(steps), int(changed[0])
+
+    def rollout_flying(self, T, seed, env_offset=0, autoreset=True, nthreads=1):
+        changed = np.zeros(1, np.int64)
+        steps = lib().igo_batch_rollout_flying(self.handles, self.n, T, seed, env_offset,
+                                               int(autoreset), nthreads, _p(changed))
         return int(steps), int(changed[0])
 
     def internals(self):

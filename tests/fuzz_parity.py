@@ -30,6 +30,18 @@ def targets(rng, n, with_start):
     return tg, st
 
 
+def full_grids(rng, tg):
+    """Subtasks-style full structures: a superset of each target (tasks/task.py:63-66: the user task's admissible
+    translations come from it), which changes GridWorld.max_int at reset and so SizeReward's first reward."""
+    fg = tg.copy()
+    for e in range(len(fg)):
+        for _ in range(rng.randint(0, 8)):
+            y, x, z = rng.randint(3), rng.randint(11), rng.randint(11)
+            if fg[e, y, x, z] == 0:
+                fg[e, y, x, z] = rng.randint(1, 7)
+    return fg
+
+
 def compare(env, ob, where):
     torch.cuda.synchronize()
     for name, a, b in (('done', env.done.cpu().numpy(), ob.done),
@@ -57,6 +69,7 @@ def main():
         with_start = rng.rand() < 0.5
         T = int(rng.choice([30, 90]))
         tg, st = targets(rng, n, with_start)
+        fg = full_grids(rng, tg) if rng.rand() < 0.4 else None
         # a third of the cases: arbitrary initial poses -- off the 5-degree lattice (general trig path, oracle in
         # device-trig mode), up to the edge of the validated range (clamped occupancy keys, agents outside the zone)
         poses = None
@@ -66,12 +79,12 @@ def main():
             if rng.rand() < 0.5:   # half of them on the lattice, at the border
                 poses[:, 3:] = np.round(poses[:, 3:] / 5.0) * 5.0
                 poses[:, [0, 2]] = np.round(poses[:, [0, 2]] * 4.0) / 4.0
-        desc = f'case {c}: n={n} gs={gs} {mode} autoreset={autoreset} start={with_start} poses={poses is not None} {kw}'
+        desc = f'case {c}: n={n} gs={gs} {mode} autoreset={autoreset} start={with_start} full_grid={fg is not None} poses={poses is not None} {kw}'
         env = VecGridWorld(n, action_space=mode, autoreset=autoreset, lanes_per_env=gs, **kw)
-        env.set_tasks(tg, st, init_pose=poses)
+        env.set_tasks(tg, st, full_grids=fg, init_pose=poses)
         env.reset()
         ob = O.OracleBatch(n, action_space=mode, **kw)
-        ob.set_tasks(tg, st)
+        ob.set_tasks(tg, st, full_grids=fg)
         if poses is not None:
             ob.set_initial_pose(poses)
         ob.reset()

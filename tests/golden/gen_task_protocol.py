@@ -131,6 +131,11 @@ def main():
         out['sub_%s_out' % tag] = np.array(res, np.int32)
         out['sub_%s_chat' % tag] = st.current.chat
         out['sub_%s_last' % tag] = st.current.last_instruction
+    # ---- Tasks.to_sparse on a dense array, exactly as the reference returns it (tasks/task.py:178-187: the
+    # nonzero() indices (y, x, z) are unpacked as (x, y, z), i.e. (y_idx - 5, x_idx - 1, z_idx - 5, id))
+    dense = goals['C17'].astype(np.int32)
+    out['to_sparse_in'] = dense.astype(np.int8)
+    out['to_sparse_out'] = np.array([[int(v) for v in b] for b in Tasks.to_sparse(dense)], np.int32)
     path = os.path.join(HERE, 's10_task_protocol.npz')
     np.savez_compressed(path, **out)
     print('s10_task_protocol: %d get_intersection queries, %d step sequences, subtasks goals %s / %s -> %.0f KiB' % (

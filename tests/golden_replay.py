@@ -107,6 +107,84 @@ def replay(fx, driver, check_internal=True, max_steps=None, float_bits=True):
     return E * T
 
 
+SUBTASK_FIXTURES = ['s11_subtasks_env', 's11_subtasks_env_nosize']
+
+
+def load_subtasks_fixture(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    fx = {k: z[k] for k in z.files}
+    fx['kwargs'] = json.loads(str(fx['kwargs']))
+    fx['name'] = name
+    return fx
+
+
+def subtasks_table(fx):
+    """Task table of a Subtasks fixture: row e * R + r = the task env e was given for its episode r (target of
+    turn k, start = structure of turn k - 1, full_grid = the final structure; tasks/task.py:260-286)."""
+    E, R = fx['ep_targets'].shape[:2]
+    tg = fx['ep_targets'].reshape(E * R, 9, 11, 11)
+    st = fx['ep_starts'].reshape(E * R, 9, 11, 11)
+    fg = np.repeat(fx['full_grids'], R, axis=0)
+    return tg, st, fg
+
+
+def replay_subtasks(fx, driver, check_internal=True):
+    """Replays an env-level set_task_generator(Subtasks) fixture (tests/golden/gen_subtasks_env.py): every reset
+    gives the env the task row the reference's generator produced for that episode.  The driver additionally
+    exposes  set_task_table(targets, starts, full_grids)  and  assign_tasks(mask[E], rows[E]).
+    Returns the number of env-steps checked."""
+    E, T = fx['done'].shape
+    R = fx['ep_targets'].shape[1]
+    name = fx['name']
+    tg, st, fg = subtasks_table(fx)
+    driver.set_task_table(tg, st, fg)
+    ar = np.arange(E)
+    grid = np.zeros((E, 1089), np.int8)
+    for t in range(T):
+        rb = fx['reset_before'][:, t].astype(bool) if t else np.ones(E, bool)
+        if rb.any():
+            ep = fx['episode'][:, t]
+            driver.assign_tasks(rb, ar * R + ep)
+            driver.reset(rb)
+            out = driver.outputs()
+            grid[rb] = fx['ep_starts'][ar[rb], ep[rb]].reshape(-1, 1089)
+            assert np.array_equal(out['grid'].reshape(E, -1)[rb], grid[rb]), f'{name}: step {t} reset grid'
+            assert np.array_equal(out['inventory'][rb], fx['ep_reset_inventory'][ar[rb], ep[rb]]), f'{name}: step {t} reset inventory'
+            assert not np.asarray(out['agentPos'])[rb].any(), f'{name}: step {t} reset agentPos'
+            if 'env_max_int' in out:
+                assert np.array_equal(out['env_max_int'][rb], fx['ep_env_max_int'][ar[rb], ep[rb]]), \
+                    f'{name}: step {t} GridWorld.max_int at reset {out["env_max_int"][rb]} vs {fx["ep_env_max_int"][ar[rb], ep[rb]]}'
+        driver.step_walking(fx['actions'][:, t])
+        out = driver.outputs()
+        idx = fx['grid_change_idx'][:, t].astype(np.int64)
+        ch = idx >= 0
+        grid[ar[ch], idx[ch]] = fx['grid_change_val'][:, t][ch]
+
+        def bad(mask):
+            e = int(np.nonzero(mask)[0][0])
+            return f'{name}: env {e} step {t}'
+        m = out['done'].astype(bool) != fx['done'][:, t].astype(bool)
+        assert not m.any(), bad(m) + f' done {out["done"][m][:1]} vs {fx["done"][:, t][m][:1]}'
+        m = np.asarray(out['reward'], np.float32) != fx['reward'][:, t].astype(np.float32)
+        assert not m.any(), bad(m) + f' reward {out["reward"][m][:1]} vs {fx["reward"][:, t][m][:1]}'
+        m = (out['grid'].reshape(E, -1) != grid).any(-1)
+        assert not m.any(), bad(m) + ' grid'
+        m = (out['inventory'] != fx['inventory'][:, t]).any(-1)
+        assert not m.any(), bad(m) + ' inventory'
+        m = (bits32(out['agentPos']) != bits32(fx['agentPos'][:, t])).any(-1)
+        assert not m.any(), bad(m) + ' agentPos'
+        m = bits32(out['compass']) != bits32(fx['compass'][:, t])
+        assert not m.any(), bad(m) + ' compass'
+        if 'syn_max_int' in out:
+            m = out['syn_max_int'] != fx['syn_max_int'][:, t]
+            assert not m.any(), bad(m) + f' synthetic max_int {out["syn_max_int"][m][:1]} vs {fx["syn_max_int"][:, t][m][:1]}'
+        if check_internal and out.get('internal') is not None:
+            m = (bits64(out['internal']) != bits64(fx['internal'][:, t])).any(-1)
+            assert not m.any(), bad(m) + ' internal'
+    assert np.array_equal(grid, fx['grid_final'].reshape(E, -1))
+    return E * T
+
+
 class OracleDriver:
     """oracle.OracleBatch behind the replay interface (CPU)."""
 
@@ -132,7 +210,18 @@ class OracleDriver:
     def step_walking_dict(self, buttons, cam):
         self.b.step_walking_dict(buttons, cam)
 
+    def set_task_table(self, targets, starts, full_grids):
+        self._table = (targets, starts, full_grids)
+
+    def assign_tasks(self, mask, rows):
+        tg, st, fg = self._table
+        for e in np.nonzero(mask)[0]:
+            self.b.envs[e].set_task(tg[rows[e]], st[rows[e]], fg[rows[e]])
+
     def outputs(self):
         b = self.b
+        ts = [e.task_state() for e in b.envs]
         return dict(agentPos=b.agentPos, inventory=b.inventory, compass=b.compass, reward=b.reward,
-                    done=b.done, grid=b.grid, internal=b.internals())
+                    done=b.done, grid=b.grid, internal=b.internals(),
+                    env_max_int=np.array([s['env_max_int'] for s in ts]),
+                    syn_max_int=np.array([s['syn_max_int'] for s in ts]))

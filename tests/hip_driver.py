@@ -35,10 +35,25 @@ class HipDriver:
     def step_walking_dict(self, buttons, cam):
         self.env.step(dict(buttons=np.asarray(buttons, np.uint8), camera=np.asarray(cam, np.float32)))
 
+    def set_task_table(self, targets, starts, full_grids):
+        """One row per (env, episode) task of a Subtasks fixture; needs num_tasks >= len(targets)."""
+        self.env.set_tasks(targets, starts, full_grids=full_grids, env_task=np.zeros(self.env.num_envs, np.int32))
+        self._with_table = True
+
+    def assign_tasks(self, mask, rows):
+        et = self.env.env_task.cpu().numpy()
+        et[np.asarray(mask, bool)] = np.asarray(rows, np.int32)[np.asarray(mask, bool)]
+        self.env.env_task.copy_(torch.as_tensor(et))
+
     def outputs(self):
         e = self.env
         torch.cuda.synchronize()
-        return dict(agentPos=e.agent_pos.cpu().numpy(), inventory=e.inventory.cpu().numpy(),
+        extra = {}
+        if getattr(self, '_with_table', False):
+            meta = e.task_meta.cpu().numpy()[e.env_task.cpu().numpy().astype(np.int64)]
+            extra = dict(env_max_int=meta[:, 42:44].copy().view(np.int16)[:, 0].astype(np.int64),
+                         syn_max_int=e.task_state()['max_int'])
+        return dict(**extra, agentPos=e.agent_pos.cpu().numpy(), inventory=e.inventory.cpu().numpy(),
                     compass=e.compass.cpu().numpy(), reward=e.reward.cpu().numpy(),
                     done=e.done.cpu().numpy(), grid=e.grid.cpu().numpy().reshape(e.num_envs, -1),
                     internal=e.internals())

@@ -38,6 +38,9 @@ WORKER = textwrap.dedent('''
     gd.barrier()
     tot, mx = gd.reduce_window(steps, el)
     counts = gd.gather_counts(steps)
+    via = gd.gather_counts_rccl(steps, None)   # no GPU here: the documented gloo path
+    assert via == (counts, 'gloo'), via
+    assert gd.reduce_windows([0.1 * (rank + 1), 0.3 - 0.1 * rank]) == [0.2, 0.3]
     if rank == 0:
         print(json.dumps(dict(total=tot, max_elapsed=mx, counts=counts, lo=lo, hi=hi, expect=total * 10, nb_us=nb_us,
                               released_after_late_rank=stamps[0] >= stamps[1])))
@@ -97,3 +100,4 @@ def test_bench_self_launches_n_ranks():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['ranks'] == [0, 1]
     assert d['total_steps'] == 2 * 65536 * 20 and d['steps'] == 20 and d['warmup'] == 5
+    assert d['windows_max'] == [2e-3, 4e-3]   # per window the max over the two ranks

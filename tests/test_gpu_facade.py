@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def _sparse(dense):
     from gridworld_amd import Tasks
-    return Tasks.to_sparse(np.asarray(dense, np.int32))
+    return Tasks.dense_to_sparse(np.asarray(dense, np.int32))
 
 
 @pytest.mark.parametrize('name,envs', [('s5_scripted', range(9)), ('s2_walk_cdm', [0, 7]),
@@ -46,6 +46,41 @@ def test_facade_matches_reference(name, envs):
             # float32 observations bit-exact, flying included (A-fly contract)
             assert np.array_equal(obs['agentPos'].view(np.uint32), fx['agentPos'][e, t].view(np.uint32)), (name, e, t)
             assert obs['compass'][0] == fx['compass'][e, t]
+
+
+@pytest.mark.parametrize('name', GR.SUBTASK_FIXTURES)
+def test_facade_subtasks_generator_matches_reference(name):
+    """The reference's own calling sequence with a task generator: env.set_task_generator(Subtasks(dialog,
+    structure_seq)); env.reset() draws the turn from np.random exactly as the reference does
+    (tasks/task.py:225-243), so with the recorded seed the port's Subtasks walks through the same episodes:
+    turns, GridWorld.max_int at every reset, observations, rewards and dones."""
+    import json
+    import gridworld_amd as G
+    fx = GR.load_subtasks_fixture(name)
+    specs = json.loads(str(fx['specs']))
+    for e in (0, 3, 5, 10, 12):
+        np.random.seed(int(fx['np_seed'][e]))
+        env = G.make('IGLUGridworld-v0', vector_state=True, render=False, **fx['kwargs'])
+        seq = [[tuple(b) for b in turn] for turn in specs[e]['seq']]
+        st = G.Subtasks(specs[e]['dialog'], seq)
+        env.set_task_generator(st)
+        ep = -1
+        done = True
+        for t in range(fx['done'].shape[1]):
+            if done:
+                obs = env.reset()
+                ep += 1
+                assert (st.task_start, st.task_goal) == tuple(fx['ep_turn'][e, ep]), (e, ep)
+                assert env.unwrapped.max_int == fx['ep_env_max_int'][e, ep], (e, ep)
+                assert np.array_equal(obs['grid'], fx['ep_starts'][e, ep])
+                assert np.array_equal(obs['inventory'], fx['ep_reset_inventory'][e, ep])
+                assert np.array_equal(env.task.target_grid, fx['ep_targets'][e, ep])
+            assert bool(fx['reset_before'][e, t]) == (done and t > 0)
+            obs, reward, done, _ = env.step(int(fx['actions'][e, t]))
+            assert done == bool(fx['done'][e, t]) and reward == fx['reward'][e, t], (name, e, t, reward)
+            assert np.array_equal(obs['agentPos'].view(np.uint32), fx['agentPos'][e, t].view(np.uint32)), (name, e, t)
+            assert np.array_equal(obs['inventory'], fx['inventory'][e, t])
+        assert ep + 1 == fx['n_episodes'][e]
 
 
 def test_facade_errors_and_spaces():

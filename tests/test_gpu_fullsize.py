@@ -127,3 +127,87 @@ def test_flying_full_size_invariants():
     counts = np.stack([(grid == c + 1).sum(1) for c in range(6)], axis=1)
     assert np.array_equal(env.inventory.cpu().numpy(), (20 - counts).astype(np.float32))
     assert np.array_equal(env.task_state()['prev_size'], (grid != 0).sum(1))
+
+
+def test_config4_workload_on_one_gpu_equals_eight_rank_shards():
+    """BASELINE configs[4]: 524,288 parallel envs, walking, random targets, sharded over 8 GPUs -- run here on ONE GPU
+    (it fits: 2.6 GB) and compared with the eight 65,536-env shards a node would run, each in its own context with
+    env_index_base = rank * 65,536 (igw_config.env_index_base keys the on-device RandomTasks generator) and
+    rank-offset action streams, exactly as bench.py sets its ranks up.  Sharding must not change a single byte."""
+    from gridworld_amd import VecGridWorld
+    R, n = 8, N
+    T = 70
+    kw = dict(size_reward=False, autoreset=True, max_steps=30)   # two auto-resets: the generator runs inside the step
+    rt = dict(seed=777, max_blocks=20, height_levels=1, max_dist=2, num_colors=6)
+
+    def run(num, base):
+        env = VecGridWorld(num, env_index_base=base, **kw)
+        env.set_random_tasks(**rt)
+        env.reset()
+        acts = env.fill_actions(T, seed=4321, env_offset=base)
+        for t in range(T):
+            env.step_walking_ptr(acts[t])
+        torch.cuda.synchronize()
+        return env
+
+    big = run(R * n, 0)
+    st = big.stats()
+    assert st['resets'] >= 2 * R * n and st['changed'] > 0
+    ts = (big.task_target[:, :1089] != 0).sum(1)
+    assert int(ts.min()) >= 1 and int(ts.max()) == 20 and big.task_target.unique().numel() == 7   # rt20-shaped targets
+    for r in range(R):
+        part = run(n, r * n)
+        sl = slice(r * n, (r + 1) * n)
+        for name in ('grid_buf', 'agent_buf', 'hist_buf', 'occ_buf', 'task_target', 'task_meta', 'episode',
+                     'agent_pos', 'inventory', 'reward', 'done'):
+            assert torch.equal(getattr(part, name), getattr(big, name)[sl]), (r, name)
+        del part
+
+
+def test_cdm_workload_full_size_properties():
+    """65,536 envs tiled from the real IGLU targets (tests/golden/cdm_goals.npz) with random partial starting grids:
+    has_start rows, task_start reads on every change, negative synthetic ids, inventories below 20 and the stale-cache
+    (`dirty`) path at scale -- invariants over the whole batch, a sample replayed through the CPU oracle."""
+    import os
+    from gridworld_amd import VecGridWorld, workloads
+    from oracle import oracle as O
+    from test_gpu_parity import _check_occ, _check_hist
+    goals = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cdm_goals.npz'))['dense']
+    T = 140
+    kw = dict(size_reward=False, max_steps=60)
+    tg, st = workloads.cdm(N, 5, goals)
+    env = VecGridWorld(N, autoreset=True, **kw)
+    env.set_tasks(tg.to(env.device), st.to(env.device))
+    env.reset()
+    acts = env.fill_actions(T, seed=606)
+    seen_dirty = 0
+    for t in range(T):
+        env.step_walking_ptr(acts[t])
+        if t % 35 == 34:
+            seen_dirty += int(env.task_state()['dirty'].sum())
+    torch.cuda.synchronize()
+    tgn, stn = tg.numpy(), st.numpy()
+    grid = env.grid.cpu().numpy().reshape(N, -1)
+    stats = env.stats()
+    assert stats['resets'] >= 2 * N and stats['changed'] > 0
+    assert stats['rescans'] > stats['changed']        # cell changes that left the block count alone (recolour in place)
+    assert seen_dirty > 0                             # ... which is the stale-cache path of tasks/task.py:112
+    _check_occ(env)
+    # inventory conservation with a starting grid: 20 - blocks of that colour in the world (env.py:243-246 + callbacks)
+    counts = np.stack([(grid == c + 1).sum(1) for c in range(6)], axis=1)
+    assert np.array_equal(env.inventory.cpu().numpy(), (20 - counts).astype(np.float32))
+    syn = grid.astype(np.int32) - stn.reshape(N, -1)
+    ts = env.task_state()
+    assert np.array_equal(ts['prev_size'], (syn != 0).sum(1))
+    _check_hist(env, tgn, starts=stn, sample=range(0, N, 1499))
+    idx = np.random.RandomState(12).choice(N, 192, replace=False)
+    a_np = acts.cpu().numpy()[:, idx]
+    ob = O.OracleBatch(len(idx), **kw)
+    ob.set_tasks(tgn[idx], stn[idx])
+    ob.reset()
+    for t in range(T):
+        ob.step_walking(a_np[t], autoreset=True, nthreads=8)
+    assert np.array_equal(grid[idx], ob.grid)
+    assert np.array_equal(env.internals()[idx].view(np.uint64), ob.internals().view(np.uint64))
+    assert np.array_equal(env.reward.cpu().numpy()[idx], ob.reward)
+    assert np.array_equal(env.inventory.cpu().numpy()[idx], ob.inventory)

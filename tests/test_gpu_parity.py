@@ -49,6 +49,66 @@ def test_task_vectors():
     assert np.array_equal(am.reshape(P, G, 3), z['fg_argmax'])
 
 
+@pytest.mark.parametrize('gs', [0, 64, 4, 1])
+@pytest.mark.parametrize('name', GR.SUBTASK_FIXTURES)
+def test_subtasks_env_fixture(name, gs):
+    """env.set_task_generator(Subtasks(...)) episodes recorded from the reference, through
+    set_tasks(targets, starts, full_grids=...): igw_prepare_tasks' full_grid -> env_max_int path
+    (tasks/task.py:63-72, 260-286; env.py:227-241) and the SizeReward it feeds at the first step (env.py:325-331)."""
+    from hip_driver import HipDriver
+    fx = GR.load_subtasks_fixture(name)
+    E, R = fx['ep_targets'].shape[:2]
+    drv = HipDriver(dict(targets=fx['full_grids'], kwargs=fx['kwargs']), lanes_per_env=gs, num_tasks=E * R)
+    assert GR.replay_subtasks(fx, drv) == fx['done'].size
+    # every row of the table (also the ones no episode used), not only the rows the replay touched
+    meta = drv.env.task_meta.cpu().numpy()
+    got = meta[:, 42:44].copy().view(np.int16)[:, 0].reshape(E, R)
+    used = np.arange(R)[None, :] < fx['n_episodes'][:, None]
+    assert np.array_equal(got[used], fx['ep_env_max_int'][used])
+    assert (fx['ep_env_max_int'][used] > 0).sum() > 20
+
+
+def test_env_max_int_with_full_grid_equals_task_eval():
+    """task_meta.env_max_int (prepare_tasks_kernel) == Task(target, full_grid).maximal_intersection(start)
+    through the separately pinned igw_task_eval and through the oracle, for random rows incl. invariant=False."""
+    from gridworld_amd import VecGridWorld, task_eval
+    from oracle import oracle as O
+    rng = np.random.RandomState(4242)
+    n = 300
+    fg = np.zeros((n, 9, 11, 11), np.int8)
+    tg = np.zeros_like(fg)
+    st = np.zeros_like(fg)
+    for e in range(n):
+        k = rng.randint(2, 30)
+        cells = rng.permutation(1089)[:k]
+        lv = rng.randint(1, 4)
+        cells = (cells % (121 * lv))
+        x0, z0 = rng.randint(0, 6), rng.randint(0, 6)   # a structure that does not fill the zone: translations exist
+        for c in cells:
+            y, r = divmod(int(c), 121)
+            fg[e, y, x0 + (r // 11) % 6, z0 + (r % 11) % 6] = rng.randint(1, 7)
+        nz = np.argwhere(fg[e] != 0)
+        order = rng.permutation(len(nz))
+        a, b = sorted(rng.randint(0, len(nz) + 1, size=2))
+        for i in order[:b]:
+            tg[e][tuple(nz[i])] = fg[e][tuple(nz[i])]
+        for i in order[:a]:
+            st[e][tuple(nz[i])] = fg[e][tuple(nz[i])]
+        if rng.rand() < 0.3:      # the start was built somewhere else / rotated: max_int finds it
+            st[e] = np.roll(np.rot90(st[e], k=rng.randint(4), axes=(1, 2)), (rng.randint(-1, 2), rng.randint(-1, 2)), axis=(1, 2))
+    inv = (rng.rand(n) < 0.8).astype(np.uint8)
+    env = VecGridWorld(n, size_reward=True)
+    env.set_tasks(tg, st, full_grids=fg, invariant=inv)
+    torch.cuda.synchronize()
+    got = env.task_meta.cpu().numpy()[:, 42:44].copy().view(np.int16)[:, 0]
+    for flag in (0, 1):
+        m = inv == flag
+        mi, _, _ = task_eval(tg[m], st[m], full_grids=fg[m], invariant=bool(flag))
+        assert np.array_equal(got[m], mi)
+    want = np.array([O.task_eval(tg[e], st[e], full_grid=fg[e], invariant=bool(inv[e]))['max_int'] for e in range(n)])
+    assert np.array_equal(got, want) and (want > 0).sum() > 50
+
+
 def test_env_max_int_at_reset():
     """GridWorld.max_int (env.py:241) lands in the task metadata and drives SizeReward."""
     from gridworld_amd import VecGridWorld

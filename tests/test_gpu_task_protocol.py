@@ -47,7 +47,7 @@ def test_step_intersection_sequences_match_reference():
     z = _z('s10_task_protocol.npz')
     for k in range(len(z['si_targets'])):
         use_full, inv = z['si_flags'][k]
-        t = Task('', z['si_targets'][k].astype(np.int32), starting_grid=Tasks.to_sparse(z['si_starts'][k].astype(np.int32)),
+        t = Task('', z['si_targets'][k].astype(np.int32), starting_grid=Tasks.dense_to_sparse(z['si_starts'][k].astype(np.int32)),
                  full_grid=z['si_fulls'][k].astype(np.int32) if use_full else None, invariant=bool(inv))
         t.reset()
         assert (t.max_int, t.prev_grid_size) == tuple(z['si_reset'][k]), k

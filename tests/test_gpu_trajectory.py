@@ -136,7 +136,44 @@ def test_input_validation_and_counters():
     env.step(dict(movement=mv, camera=torch.zeros((n, 2)), inventory=inv, placement=torch.zeros(n, dtype=torch.int32)))
     torch.cuda.synchronize()
     assert env.stats()['bad_actions'] == 2 and np.isfinite(env.internals()).all()
-    w = VecGridWorld(n)
+    # A finite but huge camera delta would spin the reference's `while yaw > 360: yaw -= 360` forever (a hung
+    # kernel): host data raises, device data (not read back) runs as a no-op component and is counted.
+    cam = torch.zeros((n, 2)); cam[4, 0] = 1e30; cam[9, 1] = -3e7; cam[11, 0] = float('inf')
+    zero = dict(movement=torch.zeros((n, 3)), inventory=torch.zeros(n, dtype=torch.int32), placement=torch.zeros(n, dtype=torch.int32))
+    with pytest.raises(ValueError):
+        env.step(dict(camera=cam, **zero))
+    before = env.internals().copy()
+    env.step(dict(camera=cam.to(env.device), **zero))
+    torch.cuda.synchronize()
+    assert env.stats()['bad_actions'] == 2 + 3
+    after = env.internals()
+    assert np.isfinite(after).all() and np.array_equal(after[:, 3:5], before[:, 3:5])   # yaw / pitch untouched
+    with pytest.raises(ValueError):
+        env.rollout_actions(dict(movement=torch.zeros((2, n, 3)), camera=cam.expand(2, n, 2), inventory=torch.zeros((2, n), dtype=torch.int32),
+                                 placement=torch.zeros((2, n), dtype=torch.int32)))
+    env.rollout_actions(dict(movement=torch.zeros((2, n, 3)), camera=cam.expand(2, n, 2).to(env.device),
+                             inventory=torch.zeros((2, n), dtype=torch.int32), placement=torch.zeros((2, n), dtype=torch.int32)))
+    torch.cuda.synchronize()
+    assert env.stats()['bad_actions'] == 5 + 6 and np.array_equal(env.internals()[:, 3:5], before[:, 3:5])
+    wd = VecGridWorld(n, discretize=False, size_reward=False)
+    wd.set_tasks(tg)
+    wd.reset()
+    wd.step(dict(buttons=torch.zeros((n, 8), dtype=torch.uint8), camera=cam.to(wd.device)))
+    torch.cuda.synchronize()
+    assert wd.stats()['bad_actions'] == 3 and np.all(wd.internals()[:, 3:5] == 0)
+    with pytest.raises(TypeError):
+        VecGridWorld(n, max_step=100)          # a misspelt create_env kwarg is an error, as in the reference
+    # the fused loops do not write the episode log: refused while it is enabled (C ABI: IGW_ERR_INVALID)
+    w = VecGridWorld(n, autoreset=True)
+    w.set_tasks(tg)
+    w.reset()
+    w.enable_trajectory_log(2)
+    with pytest.raises(IgwError):
+        w.rollout(4, seed=1)
+    acts4 = w.fill_actions(4, seed=1)
+    assert w.lib.igw_rollout_walking_actions(w.ctx, acts4.data_ptr(), 4, None, None, w._stream()) == -1
+    w.disable_trajectory_log()
+    w.rollout(4, seed=1)
     with pytest.raises(ValueError):
         w.step(torch.zeros(n + 1, dtype=torch.int32))
     with pytest.raises(IgwError):
@@ -158,7 +195,7 @@ def test_logged_wrapper_on_the_facade(tmp_path):
     env = Logged(G.make('IGLUGridworldVector-v0', **fx['kwargs']))
     env.set_path(str(tmp_path))
     env.set_desc('facade', 3)
-    env.set_task(G.Task('', fx['targets'][e].astype(np.int32), starting_grid=G.Tasks.to_sparse(fx['starts'][e].astype(np.int32))))
+    env.set_task(G.Task('', fx['targets'][e].astype(np.int32), starting_grid=G.Tasks.dense_to_sparse(fx['starts'][e].astype(np.int32))))
     env.reset()
     assert env.max_steps == fx['kwargs']['max_steps']          # attribute pass-through to the wrapped env
     n_done = 0

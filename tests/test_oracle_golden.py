@@ -14,6 +14,17 @@ def test_oracle_replays_fixture(name):
     assert n == fx['done'].size
 
 
+@pytest.mark.parametrize('name', GR.SUBTASK_FIXTURES)
+def test_oracle_replays_subtasks_episodes(name):
+    """env.set_task_generator(Subtasks(...)) episodes recorded from the reference: start = turn k - 1, target =
+    turn k, full_grid = final structure; GridWorld.max_int at every reset and the SizeReward it feeds
+    (tasks/task.py:63-72, 260-286; env.py:227-241, 325-331)."""
+    fx = GR.load_subtasks_fixture(name)
+    # OracleBatch.reset copies the reset observation; the batch driver steps without auto-reset
+    n = GR.replay_subtasks(fx, GR.OracleDriver(dict(targets=fx['full_grids'], kwargs=fx['kwargs'])))
+    assert n == fx['done'].size
+
+
 def test_oracle_env_max_int_and_syn_max_int():
     """GridWorld.max_int at reset (env.py:241, user task) and the synthetic task's max_int."""
     for name in ('s2_walk_cdm', 's3_walk_rt20'):

@@ -1,5 +1,7 @@
 """Host Task attributes that are pure data layout (no GPU): rotations, admissible translation lists, sparse /
 dense conversion -- against the reference-recorded vectors of s6_task_vectors.npz (tests/golden/gen_golden.py)."""
+import os
+
 import numpy as np
 
 import golden_replay as GR
@@ -39,8 +41,12 @@ def test_sparse_dense_round_trip_and_reset_without_device():
     from gridworld_amd.tasks import Task, Tasks
     z = _z()
     d = z['targets'][5].astype(np.int32)
-    sp = Tasks.to_sparse(d)
+    sp = Tasks.dense_to_sparse(d)
     assert np.array_equal(Tasks.to_dense(sp), d)
+    # the reference's own to_sparse(ndarray) (task.py:178-187), bit for bit incl. its index mix-up
+    z10 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 's10_task_protocol.npz'))
+    got = Tasks.to_sparse(z10['to_sparse_in'].astype(np.int32))
+    assert [tuple(int(v) for v in b) for b in got] == [tuple(r) for r in z10['to_sparse_out'].tolist()]
     assert Tasks.to_sparse(sp) is sp and Tasks.to_dense(d) is d  # pass-through (task.py:169-170, 179)
     assert np.array_equal(Tasks.to_dense(None), np.zeros((9, 11, 11)))
     # building and resetting a task needs no GPU; only reading an intersection does
