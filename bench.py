@@ -19,8 +19,8 @@ graph capture, so the GPU is at its working clocks), so any timed window -- also
 steady-state fraction of grid-changing steps and about N/250 auto-resets per launch.
 
 A WINDOW is the contract's measurement: W untimed warm-up steps, then the clock around EXACTLY K steps,
-bracketed by a barrier + torch.cuda.synchronize() on both sides; the K timed launches are 2 eager launches
-followed by ONE HIP-graph replay of the other K - 2 (captured and instantiated before the clock; --no-graph
+bracketed by a barrier + torch.cuda.synchronize() on both sides; the K timed launches are 6 eager launches
+followed by ONE HIP-graph replay of the other K - 6 (captured and instantiated before the clock; --no-graph
 times eager launches only), so a short window is kernel-bound, not host-launch-bound.  The run makes
 --rehearsals untimed-in-spirit passes first (host code paths warm; reported) and then --windows complete measured
 windows; before EVERY pass the W + K action buffers are refilled on the device with fresh random actions (same
@@ -321,7 +321,7 @@ class Runner:
         if not args.lockstep:
             self.busy(0.0, MAX_STEPS)  # at least one episode length
         self.graph, self.head, self.timed_as = None, K, 'eager launches'
-        if not args.no_graph and K > 2:
+        if not args.no_graph and K > 8:
             self._capture()
         self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.cur_h = env._stream()
@@ -374,7 +374,10 @@ class Runner:
         is off the critical path.  With other ranks alive (an RCCL watchdog thread may touch the runtime) the capture
         is thread-local; if capture or instantiation fails the window is timed as eager launches, in this process."""
         torch, W, K = self.torch, self.W, self.K
-        head = 2
+        # eager launches while the host is still busy launching the graph (the first launch after a synchronize takes
+        # ~15 us of host time, an event record ~7, a graph launch ~20; a kernel ~14): with a head of 2 the GPU ran out
+        # of work for ~15 us before the graph arrived
+        head = min(6, K - 2)
         try:
             graph = torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream(device=self.device)

@@ -18,8 +18,10 @@ OCC_WORDS = 48
 TRAJ_BYTES = 64
 HIST_ROW = 512
 STAT_STRIPES = 64
-STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS, STAT_BAD_POSE, STAT_BAD_ACTION = 0, 1, 2, 3, 4, 5
-VERSION = 2
+STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS, STAT_BAD_POSE, STAT_BAD_ACTION, STAT_BAD_TASK = 0, 1, 2, 3, 4, 5, 6
+VERSION = 3
+LEVEL_INDEX_BYTES = 160
+TASK_INDEX_BYTES = 9 * LEVEL_INDEX_BYTES
 WALKING_DISCRETE, FLYING, WALKING_DICT = 0, 1, 2
 RESET_KEEP_SIZE = 1
 CAMERA_MAX = 1e6   # IGW_CAMERA_MAX
@@ -46,7 +48,7 @@ class Config(C.Structure):
 class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('grid', 'occ', 'hist', 'agent', 'env_task', 'task_target', 'task_start',
                                           'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass',
-                                          'reward', 'done', 'stats', 'episode')]
+                                          'reward', 'done', 'stats', 'episode', 'task_index')]
 
 
 _lib = None

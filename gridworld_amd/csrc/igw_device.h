@@ -125,6 +125,7 @@ struct KParams {
     const int8_t* task_start;
     const uint32_t* task_start_occ;
     const TaskMeta* task_meta;
+    const uint8_t* task_index;   // [T][IGW_TASK_INDEX_BYTES] colour index of the synthetic targets (include/igw.h)
     float* agent_pos;
     float* inventory;
     float* compass;

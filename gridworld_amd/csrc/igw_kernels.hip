@@ -155,12 +155,46 @@ __device__ inline uint32_t next_task(const KParams& p, int env, bool leader, int
     return ep;
 }
 
+// The colour index of a synthetic target (see "incremental maximal_intersection" below; layout in include/igw.h):
+// per y level a 160-byte block = the four rotation bounding boxes (16 B), offs[15] (start of each colour class
+// in the cell list, offs[14] = number of target cells on the level), cells[<= 121] = (x << 4 | z) of the level's
+// target cells sorted by colour class -- a counting sort by the whole wave (lane = cell, two cells per lane).
+// tgt_s: LDS copy of the synthetic target row; stage_s: 160 bytes of LDS; out_g: the task's IGW_TASK_INDEX_BYTES.
+__device__ inline int index_class(int c) { return (c == 0 || c < -7 || c > 7) ? -1 : (c < 0 ? c + 7 : c + 6); }
+__device__ inline void build_level_index_wave(const int8_t* tgt_s, const int* bb4, uint8_t* stage_s, uint8_t* out_g) {
+    const int lane = __lane_id();
+    const int c0 = lane, c1 = lane + 64;
+    const bool v1 = c1 < LEVEL;
+    const uint32_t p0 = (uint32_t)((c0 / 11) << 4 | (c0 % 11)), p1 = (uint32_t)((c1 / 11) << 4 | (c1 % 11));
+    uint4* st4 = reinterpret_cast<uint4*>(stage_s);
+    for (int y = 0; y < IGW_GRID_Y; y++) {
+        const int k0 = index_class(tgt_s[y * LEVEL + c0]), k1 = v1 ? index_class(tgt_s[y * LEVEL + c1]) : -1;
+        if (lane < IGW_LEVEL_INDEX_BYTES / 16) st4[lane] = lane == 0 ? make_uint4((uint32_t)bb4[0], (uint32_t)bb4[1], (uint32_t)bb4[2], (uint32_t)bb4[3]) : make_uint4(0, 0, 0, 0);
+        wave_sync();
+        if (__ballot(k0 >= 0 || k1 >= 0)) {  // (most levels of most targets are empty: all offsets stay 0)
+            int off = 0;
+            for (int k = 0; k < 14; k++) {
+                const uint64_t m0 = __ballot(k0 == k), m1 = __ballot(k1 == k);
+                const int n0 = __builtin_popcountll(m0);
+                if (lane == 0) stage_s[16 + k] = (uint8_t)off;
+                if (k0 == k) stage_s[32 + off + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = (uint8_t)p0;
+                if (k1 == k) stage_s[32 + off + n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint8_t)p1;
+                off += n0 + __builtin_popcountll(m1);
+            }
+            if (lane == 0) stage_s[16 + 14] = (uint8_t)off;
+        }
+        wave_sync();
+        if (lane < IGW_LEVEL_INDEX_BYTES / 16) reinterpret_cast<uint4*>(out_g + y * IGW_LEVEL_INDEX_BYTES)[lane] = st4[lane];
+        wave_sync();
+    }
+}
+
 // RandomTasks.sample_task (gridworld/tasks/task_set.py:135-157) for one env by the whole wave: per height level
 // the first block uniform over the plane, then K = min(max_blocks - 1, free window cells) further blocks on
 // distinct cells within Chebyshev distance max_dist of it.  The reference draws them one at a time by rejection,
 // i.e. uniformly without replacement, so the occupied set is a uniformly random K-subset of the window; here
 // every window cell gets a random 32-bit key and the K smallest win (ties by cell index).  Colours are iid
-// uniform in 1..num_colors.  row_s: 1104 bytes of LDS scratch.  Writes the task's target row and the generated
+// uniform in 1..num_colors.  row_s: STRIDE + IGW_LEVEL_INDEX_BYTES bytes of LDS scratch.  Writes the task's target row, its colour index and the generated
 // part of its metadata (the init pose is kept); returns the number of blocks (= target_size).
 __device__ inline int sample_random_task_wave(const KParams& p, int env, uint32_t ep, int8_t* row_s) {
     const int lane = __lane_id();
@@ -207,6 +241,14 @@ __device__ inline int sample_random_task_wave(const KParams& p, int env, uint32_
     wave_sync();
     uint4* dst = reinterpret_cast<uint4*>(const_cast<int8_t*>(p.task_target) + (size_t)env * STRIDE);
     for (int c = lane; c < CHUNKS; c += WAVE) dst[c] = r4[c];
+    {   // the colour index of the new target (what the step kernels vote from)
+        BBox bi;
+        bi.xmin = xmin; bi.xmax = xmax; bi.zmin = zmin; bi.zmax = zmax;
+        int bbi[4];
+        rot_bboxes(bi, total == 0, bbi);
+        build_level_index_wave(row_s, bbi, reinterpret_cast<uint8_t*>(row_s) + STRIDE,
+                               const_cast<uint8_t*>(p.task_index) + (size_t)env * IGW_TASK_INDEX_BYTES);
+    }
     if (lane == 0) {
         // bytes 40..69 of the metadata row (task.py:9-72 on an empty start): target_size, GridWorld.max_int = 0,
         // has_start = 0, the four rotation bounding boxes, inventory 20 x 6
@@ -505,24 +547,42 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int,
 // ---------------------------------------------------------------- incremental maximal_intersection
 // tasks/task.py:147-161 as a persistent vote histogram (one 1 KB row per env: 4 rotations x 11 x 11
 // admissible translations, 16-bit counts).  A step changes at most one cell, so only the target cells on
-// that cell's y level can gain or lose a vote.  Per changed env the wave needs 1 KB of histogram, 121 bytes
-// of the synthetic target, one byte of the starting grid and the four bounding boxes.  All of it is fetched
-// by LDS-DMA (global_load_lds: no registers, no staging instructions) as soon as the change is known --
-// BEFORE the physics sub-steps -- so the loads are in flight while the wave computes, and the update itself
-// touches LDS only: votes are LDS atomics on the staged row, the new maximum is a reduction over the row
-// (always exact: no rescan path), and only the 16-byte pieces that changed go back to HBM.
+// that cell's y level whose colour equals the cell's old or new synthetic colour lose or gain a vote.  Those
+// cells are not searched for: Task.__init__ on the device (prepare_tasks_kernel, the RandomTasks generator)
+// leaves a COLOUR INDEX of the synthetic target next to it -- per y level the target cells sorted by colour
+// (a counting sort), with the start offset of every colour class and the four rotation bounding boxes in a
+// 32-byte header (IGW_LEVEL_INDEX_BYTES = 160 per level).  Per changed env the wave needs its 1 KB histogram
+// row and the 160-byte index block of the changed cell's level.  Both are fetched by LDS-DMA
+// (global_load_lds: no registers, no staging instructions) as soon as the change is known -- BEFORE the
+// physics sub-steps -- so the loads are in flight while the wave computes.  The update itself touches LDS
+// only and has NO per-env serial code: up to four changed envs are handled side by side, sixteen lanes each
+// (lane = env slot | match slot | rotation): every lane takes one (matching target cell, rotation) pair
+// straight from the index and votes with an LDS atomic on the staged row; the new maximum is a sixteen-lane DPP
+// row reduction over the row (always exact: no rescan path, no decrement bookkeeping); the row goes back to
+// HBM from the registers of the lanes that scanned it.  A wave with one changed env and a wave with four pay
+// the same (the waves with many changes used to set the tail of the launch: +1,000 cycles per changed env).
 
 // changed envs handled together per pass (one 1 KB LDS row each).  Groups of 4+ lanes rarely see more than
 // four changes in a wave; narrow groups pack many envs per wave and pay LDS for their occupancy rows.
 template <int GS>
 constexpr int req_chunk() { return GS >= 4 ? 4 : GS == 2 ? 2 : 1; }
-constexpr int ITEMS_MAX = 128;  // >= 121: the matches of one changed env always fit
-constexpr int AUX_WORDS = 40;  // 32 dwords of target level + 1 dword with the start byte + 4 dwords of bounding boxes
+constexpr int LVL_BYTES = IGW_LEVEL_INDEX_BYTES;  // one level block of a task's colour index
+constexpr int LVL_WORDS = LVL_BYTES / 4;
+constexpr int LVL_OFFS = 16;    // byte offset of offs[N_CLASSES + 1] (bytes 0..15: the four rotation bounding boxes)
+constexpr int LVL_CELLS = 32;   // byte offset of cells[<= 121]: (x << 4 | z) of the level's target cells, by class
+constexpr int N_CLASSES = 14;   // synthetic colours -7..-1, 1..7 (grid - start with ids 0..7)
+static_assert(LVL_CELLS + LEVEL <= LVL_BYTES && LVL_OFFS + N_CLASSES + 1 <= LVL_CELLS && LVL_BYTES % 16 == 0, "level index block layout");
+static_assert(IGW_TASK_INDEX_BYTES == IGW_GRID_Y * LVL_BYTES, "task colour index layout");
+
+// class of a synthetic colour (-1: nothing can match it: 0, or outside -7..7)
+__device__ inline int colour_class(int c) { return index_class(c); }
+
 template <int R>
 struct WaveScratch {
     alignas(16) uint32_t hist[R][HIST_ROW / 2];
-    alignas(16) uint32_t aux[R][AUX_WORDS];
-    uint32_t items[ITEMS_MAX];  // compacted (target cell, changed env) matches of one chunk, see resolve_changes
+    alignas(16) uint32_t aux[R][LVL_WORDS];  // the colour-index block of each staged env's changed level
+    alignas(8) uint32_t chg[WAVE / R][2];    // the wave's changed envs in lane order: {env, level | x | z | old | new}
+    uint32_t res[WAVE / R];                  // ... and their new histogram maxima
 };
 
 template <int GS>
@@ -531,7 +591,7 @@ struct BlockShared;
 static_assert(req_chunk<4>() * (HIST_ROW / 2) >= WAVE * 10, "hit_test scratch");
 // (the RandomTasks generator builds one STRIDE-byte target row in the wave's whole scratch struct, which is idle
 // at the end of a step: resolve_resets is handed &ws[wave], not one of its members)
-static_assert(sizeof(WaveScratch<1>) >= (size_t)STRIDE && alignof(WaveScratch<1>) >= 16, "sample_random_task_wave scratch");
+static_assert(sizeof(WaveScratch<1>) >= (size_t)STRIDE + LVL_BYTES && alignof(WaveScratch<1>) >= 16, "sample_random_task_wave scratch");
 template <int GS>
 struct BlockShared {
     static constexpr int EPB = BLOCK / GS;  // envs per block
@@ -656,32 +716,24 @@ __device__ inline void glds4(const void*, uint32_t*) {}
 __device__ inline void glds4_sc1(const void*, uint32_t*) {}
 #endif
 
-// The LDS-DMA loads of one changed env into scratch slot k (whole wave).  L2: bypass this CU's L1 (the fused
-// rollout re-reads rows it stored earlier in the same launch).
+// The LDS-DMA loads of one changed env into scratch slot k (whole wave): its histogram row and the colour-index
+// block of the changed cell's level.  L2: bypass this CU's L1 (the fused rollout re-reads rows it stored earlier in
+// the same launch, and may have regenerated the task row).
 template <int R, bool L2>
-__device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, int k, int env, int task, int cell) {
+__device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, int k, int env, int task, int level) {
     const int lane = __lane_id();
     const char* hrow = reinterpret_cast<const char*>(p.hist + (size_t)env * HIST_ROW) + 16 * lane;
     if (L2) glds16_sc1(hrow, ws.hist[k]);  // cache policy sc1
     else glds16(hrow, ws.hist[k]);
-    // aux row: dwords 0-31 = the 128 bytes from the dword holding the first byte of the target level (a level is
-    // 121 bytes at an arbitrary offset of the 16-byte aligned, 1104-byte row: never leaves the row); dword 32 = the
-    // dword with the starting grid's byte of the cell; dwords 33-36 = the four bounding boxes.
-    const int8_t* t4 = p.task_target + (size_t)task * STRIDE + (cell / LEVEL) * LEVEL;
-    t4 -= reinterpret_cast<uintptr_t>(t4) & 3;
-    const int8_t* s4 = p.task_start + (size_t)task * STRIDE + cell;
-    s4 -= reinterpret_cast<uintptr_t>(s4) & 3;
-    const int8_t* b4 = p.task_meta[task].bbox;
-    // one load instruction, per-lane source (measured faster than three loads with wave-uniform bases)
-    const int8_t* src = lane < 32 ? t4 + 4 * lane : lane == 32 ? s4 : b4 + 4 * (lane - 33);
-    if (lane < 37) {
-        if (L2) glds4_sc1(src, ws.aux[k]);  // the fused rollout may have regenerated this task row earlier in the launch
-        else glds4(src, ws.aux[k]);
+    const uint8_t* blk = p.task_index + (size_t)task * IGW_TASK_INDEX_BYTES + level * LVL_BYTES + 16 * lane;
+    if (lane < LVL_BYTES / 16) {
+        if (L2) glds16_sc1(blk, ws.aux[k]);
+        else glds16(blk, ws.aux[k]);
     }
 }
 
-// The wave's changed envs are named by their leader lanes (a ballot); their parameters travel as wave-uniform
-// values (v_readlane of the leader), not through LDS.
+// The wave's changed envs are named by their leader lanes (a ballot); for the DMA their parameters travel as
+// wave-uniform values (v_readlane of the leader), not through LDS.
 __device__ inline int next_leader(uint64_t& m) {
     const int l = __builtin_ctzll(m);
     m &= m - 1;
@@ -700,138 +752,123 @@ __device__ inline uint64_t prefetch_changes(const Grp<GS>& G, const KParams& p, 
         if (m) {
             const int l = next_leader(m);
             dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
-                                     __builtin_amdgcn_readlane(ch.idx, l));
+                                     __builtin_amdgcn_readlane(ch.idx, l) / LEVEL);
         }
     }
     return mask;
 }
 
+// maximum of NON-NEGATIVE ints over each DPP row (16 lanes); valid in lane 15 of the row
+__device__ inline int row_max_nonneg(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false));  // row_shr:8
+    return v;
+}
+
 // Applies the changes (after the DMA landed) and returns, per changed env, the new maximum of its histogram.
-// Per chunk of up to R envs, three batched phases (their LDS round trips overlap over the envs): reads of the
-// staged row piece / target level / start byte / bounding boxes; votes as LDS atomics without return (they
-// pipeline); one read of the updated row per env for the maximum and the write-back of the 16-byte pieces
-// that changed.
+// start_val: the starting grid's value at the changed cell (synthetic colour = grid - start, env.py:290).
+// Everything is lane-parallel over the up to R envs of a chunk (see the section comment): env slot = lane / 16,
+// and within the sixteen lanes of a slot match slot = (lane / 4) % 4, rotation = lane % 4.
 template <int GS, bool L2>
 __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveScratch<req_chunk<GS>()>& ws,
-                                      uint64_t mask, int env, int task, const CellChange& ch) {
+                                      uint64_t mask, int env, int task, const CellChange& ch, int start_val) {
     constexpr int R = req_chunk<GS>();
     if (mask == 0) return 0;
+    // (the fused rollout arrives with its loads in flight: the break's colour, the start byte, the DMA)
+    if (L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int lane = __lane_id();
     const int E = __builtin_popcountll(mask);
-    const bool v1 = lane + 64 < LEVEL;
-    const int oldc = old_colour(ch);  // the break's colour has arrived by now
-    int hmax_l = 0;
+    // this lane's env among the changed envs of the wave: leaders below it (its own leader's bit excluded)
+    const bool grp_changed = (mask >> (lane & ~(GS - 1))) & 1ull;
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const int rank = below - ((G.gl > 0 && grp_changed) ? 1 : 0);
+    if (grp_changed && G.gl == 0) {
+        int a = old_colour(ch) - start_val, b = ch.new_val - start_val;  // old / new synthetic colour, a != b
+        a = (a < -7 || a > 7) ? 0 : a;
+        b = (b < -7 || b > 7) ? 0 : b;
+        const int rem = ch.idx % LEVEL;
+        *reinterpret_cast<uint2*>(ws.chg[rank]) =
+            make_uint2((uint32_t)env, (uint32_t)(rem / 11) | ((uint32_t)(rem % 11) << 4) | ((uint32_t)(a & 15) << 8) | ((uint32_t)(b & 15) << 12));
+    }
+    const int slot = lane >> 4, sub = lane & 15, mi = sub >> 2, q = lane & 3;
     uint64_t m = mask;
     for (int base = 0; base < E; base += R) {
-        if (base > 0 && IGW_DIAG_FLAG(p, 256)) break;  // diag 256: what the second pass of a wave with more than R changes costs
+        if (base > 0 && IGW_DIAG_FLAG(p, 256)) break;  // diag 256: what the later passes of a wave with more than R changes cost
         const int cnt = min(R, E - base);
-        int ll[R], r_env[R], r_task[R], r_cell[R], r_new[R], r_old[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            ll[k] = 0; r_env[k] = 0; r_task[k] = 0; r_cell[k] = 0; r_new[k] = 0; r_old[k] = 0;
             if (k < cnt) {
                 const int l = next_leader(m);
-                ll[k] = l;
-                r_env[k] = __builtin_amdgcn_readlane(env, l);
-                r_task[k] = __builtin_amdgcn_readlane(task, l);
-                r_cell[k] = __builtin_amdgcn_readlane(ch.idx, l);
-                r_new[k] = __builtin_amdgcn_readlane(ch.new_val, l);
-                r_old[k] = __builtin_amdgcn_readlane(oldc, l);
                 // more changed envs than scratch rows: the later chunks are fetched only now (rare)
-                if (base > 0) dma_change_inputs<R, L2>(p, ws, k, r_env[k], r_task[k], r_cell[k]);
+                if (base > 0)
+                    dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
+                                             __builtin_amdgcn_readlane(ch.idx, l) / LEVEL);
             }
         }
-        // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks
-        // and the fused rollout wait here
-        if (L2 || base > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks wait here
+        if (base > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
-        int tv0[R], tv1[R], sv[R];
-        uint4 before[R];
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            if (k < cnt) {
-                before[k] = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
-                const int8_t* trow = p.task_target + (size_t)r_task[k] * STRIDE + (r_cell[k] / LEVEL) * LEVEL;
-                const int8_t* tb = reinterpret_cast<const int8_t*>(ws.aux[k]) + (reinterpret_cast<uintptr_t>(trow) & 3);
-                tv0[k] = tb[lane];
-                tv1[k] = v1 ? tb[lane + 64] : 0;
-                sv[k] = reinterpret_cast<const int8_t*>(&ws.aux[k][32])[reinterpret_cast<uintptr_t>(p.task_start + (size_t)r_task[k] * STRIDE + r_cell[k]) & 3];
-            }
-        }
-        // Votes.  A target cell of the changed cell's level votes when its colour equals the cell's old synthetic
-        // colour (the pair stops matching: -1) or its new one (+1).  Only a handful of the 121 cells do, so the
-        // matches of the whole chunk are first compacted into a list -- every matching lane appends one word:
-        // cell | inc << 7 | slot << 8 | gx << 10 | gz << 14 -- and then four lanes take one match each, one lane
-        // per rotation: the rotation arithmetic runs once per chunk, not once per env and half-level.
-        int n_items = 0;  // wave-uniform
-        const auto vote = [&]() {  // the listed matches vote; four lanes per match, one per rotation
-            wave_sync();
-            for (int i0 = 0; i0 < n_items; i0 += WAVE / 4) {
-                const int it = i0 + (lane >> 2);
-                if (it < n_items) {
-                    const uint32_t w = ws.items[it];
-                    const int q = lane & 3, j = (int)(w & 0x7f), k = (int)((w >> 8) & 3);
-                    const bool inc = (w & 0x80u) != 0;
-                    const int gx = (int)((w >> 10) & 15), gz = (int)((w >> 14) & 15);
-                    const int bb = (int)ws.aux[k][33 + q];  // (measured faster than keeping the boxes in registers)
-                    const int tx = j / 11, tz = j % 11;
-                    // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
-                    const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
-                    const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
-                    const int xmin = (int8_t)(bb & 0xff), xmax = (int8_t)((bb >> 8) & 0xff);
-                    const int zmin = (int8_t)((bb >> 16) & 0xff), zmax = (int8_t)((bb >> 24) & 0xff);
-                    const int dx = rx - gx, dz = rz - gz, dxlo = xmax - 10, dzlo = zmax - 10;
-                    if (dx >= dxlo && dx <= xmin && dz >= dzlo && dz <= zmin) {  // admissible (task.py:62-72)
-                        const int bin = q * 121 + (dx - dxlo) * 11 + (dz - dzlo);
-                        const uint32_t one = 1u << (16 * (bin & 1));
-                        atomicAdd(&ws.hist[k][bin >> 1], inc ? one : 0u - one);
-                    }
-                }
-            }
-            wave_sync();
-            n_items = 0;
-        };
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            if (k < cnt) {
-                const int a = r_old[k] - sv[k], b = r_new[k] - sv[k];  // synthetic grid = grid - start
-                const int rem = r_cell[k] % LEVEL, gx = rem / 11, gz = rem % 11;
-                const uint32_t tag = ((uint32_t)k << 8) | ((uint32_t)gx << 10) | ((uint32_t)gz << 14);
-                // (a cell that matched before and after cannot exist: a != b)
-                const bool dec0 = tv0[k] != 0 && tv0[k] == a, inc0 = tv0[k] != 0 && tv0[k] == b;
-                const bool dec1 = tv1[k] != 0 && tv1[k] == a, inc1 = tv1[k] != 0 && tv1[k] == b;
-                const uint64_t m0 = __ballot(dec0 != inc0), m1 = __ballot(dec1 != inc1);
-                const int c0 = __builtin_popcountll(m0), c1 = __builtin_popcountll(m1);
-                if (c0 + c1) {
-                    if (n_items + c0 + c1 > ITEMS_MAX) vote();  // (a level full of one colour: 121 matches)
-                    const int r0 = n_items + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-                    const int r1 = n_items + c0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-                    if (dec0 != inc0) ws.items[r0] = (uint32_t)lane | (inc0 ? 0x80u : 0u) | tag;
-                    if (dec1 != inc1) ws.items[r1] = (uint32_t)(lane + 64) | (inc1 ? 0x80u : 0u) | tag;
-                    n_items += c0 + c1;
+        const bool my = slot < cnt;
+        const int sl = my ? slot : 0;
+        const uint2 ent = my ? *reinterpret_cast<const uint2*>(ws.chg[base + sl]) : make_uint2(0u, 0u);
+        const uint8_t* blk = reinterpret_cast<const uint8_t*>(ws.aux[sl]);
+        const int gx = (int)(ent.y & 15u), gz = (int)((ent.y >> 4) & 15u);
+        const int a = ((int)(ent.y << 20)) >> 28, b = ((int)(ent.y << 16)) >> 28;  // sign-extended 4-bit fields
+        const int ca = colour_class(a), cb = colour_class(b);
+        // the two colour classes' slices of the level's cell list
+        int oa0 = 0, oa1 = 0, ob0 = 0, ob1 = 0;
+        if (my && ca >= 0) { oa0 = blk[LVL_OFFS + ca]; oa1 = blk[LVL_OFFS + ca + 1]; }
+        if (my && cb >= 0) { ob0 = blk[LVL_OFFS + cb]; ob1 = blk[LVL_OFFS + cb + 1]; }
+        const int na = oa1 - oa0, n = na + (ob1 - ob0);
+        // rotation q's bounding box: admissible translations dx in [xmax - 10, xmin], dz in [zmax - 10, zmin] (task.py:62-72)
+        const int bb = my ? (int)reinterpret_cast<const uint32_t*>(blk)[q] : 0;
+        const int xmin = (int)(int8_t)(bb & 0xff), dxlo = (int)(int8_t)((bb >> 8) & 0xff) - 10;
+        const int zmin = (int)(int8_t)((bb >> 16) & 0xff), dzlo = (int)(int8_t)((bb >> 24) & 0xff) - 10;
+        for (int i0 = 0;; i0 += 4) {
+            const int idx = i0 + mi;
+            const bool act = idx < n;
+            if (!__any(act)) break;
+            if (act) {
+                const bool dec = idx < na;  // a target cell of the old colour stops matching, one of the new colour starts to
+                const int cell = blk[LVL_CELLS + (dec ? oa0 + idx : ob0 + (idx - na))];
+                const int tx = cell >> 4, tz = cell & 15;
+                // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
+                const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
+                const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
+                const int u = rx - gx - dxlo, v = rz - gz - dzlo;
+                if ((unsigned)u <= (unsigned)(xmin - dxlo) && (unsigned)v <= (unsigned)(zmin - dzlo)) {  // (extents <= 10: both bounds >= 0)
+                    const int bin = q * 121 + u * 11 + v;
+                    const uint32_t one = 1u << (16 * (bin & 1));
+                    atomicAdd(&ws.hist[sl][bin >> 1], dec ? 0u - one : one);
                 }
             }
         }
-        if (n_items) vote();
         wave_sync();
+        // every slot's sixteen lanes read their env's updated row once: it goes back to HBM from these registers and
+        // its maximum is a DPP row reduction (the eight 16-bit counts of a piece: packed maxima, v_pk_max_u16)
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        us2 pm = {0, 0};
+        if (my) {
+            const uint4* row = reinterpret_cast<const uint4*>(ws.hist[sl]);
+            uint4* dst = reinterpret_cast<uint4*>(p.hist + (size_t)ent.x * HIST_ROW);
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-            if (k < cnt) {
-                const uint4 now = reinterpret_cast<const uint4*>(ws.hist[k])[lane];
-                if (now.x != before[k].x || now.y != before[k].y || now.z != before[k].z || now.w != before[k].w)
-                    reinterpret_cast<uint4*>(p.hist + (size_t)r_env[k] * HIST_ROW)[lane] = now;
-                // the eight 16-bit counts of the lane: three packed maxima (v_pk_max_u16), then the two halves
-                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                const us2 pm = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(us2, now.x), __builtin_bit_cast(us2, now.y)),
-                                                         __builtin_elementwise_max(__builtin_bit_cast(us2, now.z), __builtin_bit_cast(us2, now.w)));
-                const int best = wave_max_nonneg((int)max((uint32_t)pm.x, (uint32_t)pm.y));
-                if (lane / GS == ll[k] / GS) hmax_l = best;
+            for (int j = 0; j < 4; j++) {
+                const uint4 now = row[j * 16 + sub];
+                dst[j * 16 + sub] = now;
+                pm = __builtin_elementwise_max(pm, __builtin_elementwise_max(
+                    __builtin_elementwise_max(__builtin_bit_cast(us2, now.x), __builtin_bit_cast(us2, now.y)),
+                    __builtin_elementwise_max(__builtin_bit_cast(us2, now.z), __builtin_bit_cast(us2, now.w))));
             }
         }
+        const int best = row_max_nonneg((int)max((uint32_t)pm.x, (uint32_t)pm.y));
+        if (my && sub == 15) ws.res[base + sl] = (uint32_t)best;
     }
     // a fused rollout reads the rows again in its next step: let the stores reach L2 first
     if (L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return hmax_l;
+    wave_sync();
+    return grp_changed ? (int)ws.res[rank] : 0;
 }
 
 // auto-reset rows of every done env of this wave (whole wave per env, coalesced).  With the RandomTasks
@@ -1090,7 +1127,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         env_store_pose(e, p.agent + env);
     }
     stamp(p, 4);
-    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch);
+    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch, start_val);
     const int size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
     const bool need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
     int mi = e.max_int;
@@ -1202,7 +1239,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
             world_update<GS, MODE>(G, p2, e, occ_s, mv);
             finish_break(e, ch);
         }
-        const int hmax = resolve_changes<GS, true>(G, p2, sh.ws[wave], chg_mask, env, task, ch);
+        const int hmax = resolve_changes<GS, true>(G, p2, sh.ws[wave], chg_mask, env, task, ch, start_val);
         if (active) {
             size_new = e.prev_size + syn_size_delta(ch, start_val);
             need = size_new != e.prev_size;
@@ -1267,7 +1304,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
 
 // GridWorld.reset for the masked envs: one wavefront per env (rows move coalesced)
 __global__ __launch_bounds__(BLOCK) void reset_kernel(KParams p, const uint8_t* mask, int keep_size) {
-    __shared__ alignas(16) int8_t row_s[WAVES_PER_BLOCK][STRIDE];  // RandomTasks generator scratch
+    __shared__ alignas(16) int8_t row_s[WAVES_PER_BLOCK][STRIDE + IGW_LEVEL_INDEX_BYTES];  // RandomTasks generator scratch
     const int env = blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE;
     if (env >= p.n_envs) return;
     if (mask && !mask[env]) return;
@@ -1332,6 +1369,11 @@ __global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int fir
     else zero_row_lds_wave(S);
     if (full_grid) row_to_lds_wave(F, full_grid + (size_t)i * STRIDE);
     wave_sync();
+    {   // block ids are 0..7 (env.py:85: Box(low=-1, high=7)); a cell with another id can never vote (colour index)
+        bool odd = false;
+        for (int c = lane; c < CELLS; c += WAVE) odd = odd || (unsigned)T[c] > 7u || (unsigned)S[c] > 7u;
+        if (__ballot(odd) && lane == 0) stat_add(p.stats, IGW_STAT_BAD_TASK, 1);
+    }
     // GridWorld.max_int at reset = user task on the starting grid (env.py:241); the user task's
     // admissible set comes from full_grid when given (task.py:63-66), or is [(0,0)] if not invariant
     const bool inv = invariant ? invariant[i] != 0 : true;
@@ -1385,6 +1427,9 @@ __global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int fir
         uint4* d = reinterpret_cast<uint4*>(const_cast<int8_t*>(p.task_target) + (size_t)task * STRIDE);
         for (int c = lane; c < CHUNKS; c += WAVE) d[c] = s[c];
     }
+    // the colour index of the synthetic target: what the step kernels vote from (sh.hist[wave] is free again)
+    build_level_index_wave(T, bb_syn, reinterpret_cast<uint8_t*>(sh.hist[wave]),
+                           const_cast<uint8_t*>(p.task_index) + (size_t)task * IGW_TASK_INDEX_BYTES);
     if (lane == 0) {
         TaskMeta m;
         memset(&m, 0, sizeof(m));
@@ -1640,10 +1685,11 @@ int igw_destroy(igw_ctx* ctx) {
 int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
     if (!ctx || !b) return fail(IGW_ERR_INVALID, "igw_bind_buffers: null argument");
     if (!b->grid || !b->occ || !b->hist || !b->agent || !b->env_task || !b->task_target || !b->task_start ||
-        !b->task_start_occ || !b->task_meta || !b->agent_pos || !b->inventory || !b->compass || !b->reward || !b->done)
+        !b->task_start_occ || !b->task_meta || !b->agent_pos || !b->inventory || !b->compass || !b->reward || !b->done ||
+        !b->task_index)
         return fail(IGW_ERR_INVALID, "igw_bind_buffers: a required buffer is null");
     if (((uintptr_t)b->grid | (uintptr_t)b->occ | (uintptr_t)b->hist | (uintptr_t)b->agent | (uintptr_t)b->task_target |
-         (uintptr_t)b->task_start | (uintptr_t)b->task_start_occ | (uintptr_t)b->task_meta) & 15)
+         (uintptr_t)b->task_start | (uintptr_t)b->task_start_occ | (uintptr_t)b->task_meta | (uintptr_t)b->task_index) & 15)
         return fail(IGW_ERR_INVALID, "igw_bind_buffers: grid / occ / agent / task buffers must be 16-byte aligned");
     KParams& k = ctx->kp;
     k.grid = b->grid;
@@ -1662,6 +1708,7 @@ int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
     k.done = b->done;
     k.stats = reinterpret_cast<unsigned long long*>(b->stats);
     k.episode = b->episode;
+    k.task_index = b->task_index;
     if (!k.episode) {  // features keyed by the episode counter cannot outlive it
         k.sample_tasks = 0; k.rt_enabled = 0; k.traj = nullptr; k.traj_heads = nullptr; k.traj_n = 0;
     }

@@ -68,6 +68,7 @@ class VecGridWorld:
         self.task_start = z((T, L.GRID_STRIDE), torch.int8)
         self.task_start_occ = z((T, L.OCC_WORDS), torch.int32)
         self.task_meta = z((T, L.TASK_META_BYTES), torch.uint8)
+        self.task_index = z((T, L.TASK_INDEX_BYTES), torch.uint8)   # colour index of the synthetic targets (include/igw.h)
         self.agent_pos = z((N, 5), torch.float32)
         self.inventory = z((N, 6), torch.float32)
         self.compass = z((N,), torch.float32)
@@ -89,7 +90,7 @@ class VecGridWorld:
         b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.occ_buf, self.hist_buf, self.agent_buf, self.env_task,
                                                 self.task_target, self.task_start, self.task_start_occ, self.task_meta,
                                                 self.agent_pos, self.inventory, self.compass, self.reward, self.done,
-                                                self.stats_buf, self.episode)])
+                                                self.stats_buf, self.episode, self.task_index)])
         L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(b)), 'igw_bind_buffers')
         self.grid = torch.as_strided(self.grid_buf, (N, 9, 11, 11), (L.GRID_STRIDE, 121, 11, 1))
         self.user_target = None
@@ -121,6 +122,11 @@ class VecGridWorld:
         inv = None
         if invariant is not None:
             inv = torch.as_tensor(np.broadcast_to(np.asarray(invariant, dtype=np.uint8), (T,)).copy(), device=dev)
+        for name, g in (('targets', tgt), ('starts', st)):
+            # block ids are 0..7 (the observation space's range, env.py:85); the C ABI counts offending rows
+            # (IGW_STAT_BAD_TASK) and never matches such a cell
+            if g is not None and g.numel() and (int(g.min()) < 0 or int(g.max()) > 7):
+                raise ValueError(f'{name}: block ids must be in 0..7')
         if first < 0 or first + T > self.num_tasks:
             raise ValueError(f'task rows [{first}, {first + T}) do not fit the table of {self.num_tasks}')
         for name, g in (('starts', st), ('full_grids', fg)):
@@ -209,8 +215,8 @@ class VecGridWorld:
     def state_dict(self):
         """Snapshot of the complete env state (tensors are cloned): resume / parity debugging."""
         keys = ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'env_task', 'task_target', 'task_start',
-                'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass', 'reward', 'done', 'stats_buf',
-                'episode')
+                'task_start_occ', 'task_meta', 'task_index', 'agent_pos', 'inventory', 'compass', 'reward', 'done',
+                'stats_buf', 'episode')
         return {k: getattr(self, k).clone() for k in keys}
 
     def load_state_dict(self, state):
@@ -383,7 +389,8 @@ class VecGridWorld:
         s = s.cpu()
         return {'changed': int(s[L.STAT_CHANGED]), 'resets': int(s[L.STAT_RESETS]),
                 'rollout_steps': int(s[L.STAT_STEPS]), 'rescans': int(s[L.STAT_RESCANS]),
-                'bad_poses': int(s[L.STAT_BAD_POSE]), 'bad_actions': int(s[L.STAT_BAD_ACTION])}
+                'bad_poses': int(s[L.STAT_BAD_POSE]), 'bad_actions': int(s[L.STAT_BAD_ACTION]),
+                'bad_tasks': int(s[L.STAT_BAD_TASK])}
 
     def internals(self):
         """float64 [N,8]: x, y, z, yaw, pitch, dy, time_int_steps, active_block (debug / parity)."""
@@ -423,7 +430,8 @@ class SubBatch:
         outs = (parent.agent_pos, parent.inventory, parent.compass, parent.reward, parent.done)
         self.stats_buf = torch.zeros_like(parent.stats_buf)
         ptrs = [t[lo:lo + n].data_ptr() for t in per_env] + [t.data_ptr() for t in shared] + \
-               [t[lo:lo + n].data_ptr() for t in outs] + [self.stats_buf.data_ptr(), parent.episode[lo:lo + n].data_ptr()]
+               [t[lo:lo + n].data_ptr() for t in outs] + [self.stats_buf.data_ptr(), parent.episode[lo:lo + n].data_ptr(),
+                                                          parent.task_index.data_ptr()]
         L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(L.Buffers(*ptrs))), 'igw_bind_buffers')
         sl = slice(lo, lo + n)
         self.agent_pos, self.inventory = parent.agent_pos[sl], parent.inventory[sl]

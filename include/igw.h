@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IGW_VERSION 2
+#define IGW_VERSION 3
 /* igw_config.lanes_per_env == 0 picks the group width measured fastest on an MI355X for the batch size
  * (profiles/r02_sweep_lanes*.txt): 32 lanes per env up to IGW_AUTO_32_MAX envs, 16 up to IGW_AUTO_16_MAX, 8 up to
  * IGW_AUTO_8_MAX, 4 beyond (a launch then has between about 512 and 4,096 wavefronts for 1,024 SIMDs).  64 (one
@@ -59,6 +59,15 @@ extern "C" {
 /* persistent per-env vote histogram of maximal_intersection: for each of the 4 rotations the 11 x 11
  * admissible translations (bounding-box relative), uint16 counts, row padded to 512 entries */
 #define IGW_HIST_ROW 512
+/* colour index of a task's synthetic target: what the step kernels vote from when a cell changes.  Per y level one
+ * IGW_LEVEL_INDEX_BYTES block:
+ *    0 i8 bbox[4][4]   per rotation xmin, xmax, zmin, zmax of the synthetic target (copy of the metadata's)
+ *   16 u8 offs[15]     start of each colour class in cells[]; class = colour + 7 for -7..-1, colour + 6 for 1..7
+ *                      (synthetic colours = target - start with block ids 0..7); offs[14] = cells on this level
+ *   32 u8 cells[<=121] (x+5) << 4 | (z+5) of the level's target cells, sorted by colour class
+ * written by igw_prepare_tasks and by the on-device RandomTasks generator */
+#define IGW_LEVEL_INDEX_BYTES 160
+#define IGW_TASK_INDEX_BYTES (IGW_GRID_Y * IGW_LEVEL_INDEX_BYTES)
 /* bytes of per-env agent state and of per-task metadata (layouts below) */
 #define IGW_AGENT_BYTES 64
 #define IGW_TASK_META_BYTES 128
@@ -74,6 +83,8 @@ extern "C" {
                                * movement / camera values, camera deltas beyond +-IGW_CAMERA_MAX, inventory /
                                * hotbar ids outside 0..6 (the reference raises ValueError there,
                                * core/world.py:354-355) */
+#define IGW_STAT_BAD_TASK 6   /* task rows with a block id outside 0..7 in target or starting grid (the ids of
+                               * env.py:85); the step kernels never count such a cell as a match */
 /* largest |camera delta| per step (degrees; same bound as init_pose's yaw / pitch): the reference wraps yaw by
  * repeated subtraction of 360 (core/world.py:451-456), which never ends for a finite but huge value */
 #define IGW_CAMERA_MAX 1e6
@@ -159,6 +170,7 @@ typedef struct igw_buffers {
     uint64_t* stats;       /* [IGW_STAT_STRIPES][8], caller zeroes; may be NULL */
     uint32_t* episode;     /* [N] episodes started per env (every reset adds 1); keys the on-device task samplers and
                             * the trajectory log; may be NULL unless one of those is enabled */
+    uint8_t* task_index;   /* [T][IGW_TASK_INDEX_BYTES] colour index of task_target (task table, 16-byte aligned) */
 } igw_buffers;
 
 typedef struct igw_ctx igw_ctx;

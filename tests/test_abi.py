@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f'{name} declared in include/igw.h but not exported'
     assert sorted(_lib.EXPORTS) == declared
-    assert L.igw_version() == 2
+    assert L.igw_version() == _lib.VERSION == 3
 
 
 def test_layout_constants_match_header():
@@ -33,11 +33,13 @@ def test_layout_constants_match_header():
                       ('IGW_AGENT_BYTES', _lib.AGENT_BYTES), ('IGW_TASK_META_BYTES', _lib.TASK_META_BYTES),
                       ('IGW_STAT_STRIPES', _lib.STAT_STRIPES), ('IGW_OCC_WORDS', _lib.OCC_WORDS),
                       ('IGW_TRAJ_BYTES', _lib.TRAJ_BYTES), ('IGW_VERSION', _lib.VERSION),
-                      ('IGW_STAT_BAD_POSE', _lib.STAT_BAD_POSE), ('IGW_STAT_BAD_ACTION', _lib.STAT_BAD_ACTION)):
+                      ('IGW_STAT_BAD_POSE', _lib.STAT_BAD_POSE), ('IGW_STAT_BAD_ACTION', _lib.STAT_BAD_ACTION),
+                      ('IGW_STAT_BAD_TASK', _lib.STAT_BAD_TASK), ('IGW_LEVEL_INDEX_BYTES', _lib.LEVEL_INDEX_BYTES)):
         m = re.search(r'#define\s+%s\s+(\d+)' % name, src)
         assert m and int(m.group(1)) == val, name
     assert ctypes.sizeof(_lib.Config) == 64
-    assert ctypes.sizeof(_lib.Buffers) == 16 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.Buffers) == 17 * ctypes.sizeof(ctypes.c_void_p)
+    assert _lib.TASK_INDEX_BYTES == 9 * _lib.LEVEL_INDEX_BYTES
 
 
 def test_fails_loudly_without_device():

@@ -66,6 +66,7 @@ def test_subtasks_env_fixture(name, gs):
     used = np.arange(R)[None, :] < fx['n_episodes'][:, None]
     assert np.array_equal(got[used], fx['ep_env_max_int'][used])
     assert (fx['ep_env_max_int'][used] > 0).sum() > 20
+    _check_index(drv.env, rows=np.nonzero(used.reshape(-1))[0][::7])   # synthetic targets with negative ids
 
 
 def test_env_max_int_with_full_grid_equals_task_eval():
@@ -195,6 +196,7 @@ def test_rt20_autoreset_vs_oracle(gs):
     assert st['resets'] >= n and 0.01 < st['changed'] / (n * T) < 0.3
     _check_occ(env)
     _check_hist(env, tg, sample=range(0, n, 7))
+    _check_index(env, rows=range(0, n, 11))
 
 
 def _expected_hist(target_syn, grid_syn):
@@ -232,6 +234,34 @@ def _check_hist(env, targets, starts=None, sample=None):
         assert np.array_equal(hist[e], want), f'env {e}: histogram differs from a fresh recount'
         if not ts['dirty'][e]:
             assert ts['max_int'][e] == want.max(), f'env {e}: max_int {ts["max_int"][e]} vs {want.max()}'
+
+
+def _expected_index(target_syn, bbox16):
+    """The colour index igw_prepare_tasks / the RandomTasks generator derive from a synthetic target (include/igw.h):
+    per level the rotation boxes, the class offsets and the (x << 4 | z) cell list sorted by colour class."""
+    out = np.zeros((9, 160), np.uint8)
+    for y in range(9):
+        out[y, :16] = bbox16
+        lvl = target_syn[y].reshape(-1).astype(np.int32)
+        pos = 0
+        for k in range(14):
+            colour = k - 7 if k < 7 else k - 6
+            out[y, 16 + k] = pos
+            for c in np.nonzero(lvl == colour)[0]:
+                out[y, 32 + pos] = (c // 11) << 4 | (c % 11)
+                pos += 1
+        out[y, 16 + 14] = pos
+    return out.reshape(-1)
+
+
+def _check_index(env, rows=None):
+    """task_index == the index recomputed on the host from task_target and the metadata's boxes."""
+    torch.cuda.synchronize()
+    tt = env.task_target.cpu().numpy()[:, :1089].reshape(-1, 9, 11, 11)
+    meta = env.task_meta.cpu().numpy()
+    got = env.task_index.cpu().numpy()
+    for r in (range(len(tt)) if rows is None else rows):
+        assert np.array_equal(got[r], _expected_index(tt[r], meta[r, 48:64])), f'task row {r}: colour index'
 
 
 def _check_occ(env):

@@ -66,6 +66,15 @@ def test_distribution_matches_host_mirror(kw):
         assert abs((host[:, :L][host[:, :L] != 0] == c).mean() - 1 / kw['num_colors']) < 0.02
 
 
+def test_generated_tasks_carry_their_colour_index():
+    """The generator also writes the colour index the step kernels vote from (include/igw.h), for reset_kernel and
+    for the in-step auto-reset alike."""
+    from test_gpu_parity import _check_index
+    for rounds in (1, 3):
+        _, env = _device_samples(640, rounds, seed=21, max_blocks=7, height_levels=3, max_dist=2, num_colors=5)
+        _check_index(env, rows=range(0, 640, 9))
+
+
 def test_generated_tasks_are_deterministic_and_seeded():
     kw = dict(max_blocks=8, height_levels=1, max_dist=2, num_colors=4)
     a, _ = _device_samples(512, 5, seed=5, **kw)
