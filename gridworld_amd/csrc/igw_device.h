@@ -518,6 +518,18 @@ __device__ inline void key_unpack(int key, int& x, int& y, int& z) {
     x = (key & 0xff) - 6; y = ((key >> 8) & 0xff) - 4; z = ((key >> 16) & 0xff) - 6;
 }
 
+// byte `j` of `w` := min(v, lim) (unsigned), the other bytes of w untouched: v_min_u32 with a byte destination.
+__device__ inline void sdwa_min_into_byte(uint32_t& w, uint32_t v, uint32_t lim, int j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (j == 0) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(v), "v"(lim));
+    else if (j == 1) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(v), "v"(lim));
+    else if (j == 2) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(v), "v"(lim));
+    else asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(v), "v"(lim));
+#else
+    w = (w & ~(0xffu << (8 * j))) | ((v < lim ? v : lim) << (8 * j));
+#endif
+}
+
 // Sample k is position + k sequential additions of vector/5 (the reference's recurrence, so the
 // rounding of every partial sum is reproduced).
 // `scratch`: WAVE * 10 words of LDS owned by the wave (groups of four lanes only; see there).
@@ -552,16 +564,21 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
         uint32_t* const mine = scratch + G.lane;
         int kidx[ROUNDS];
         uint32_t word[ROUNDS];
+        const uint32_t twelve = 12u;
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
-            int w = 0;
+            uint32_t w = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                w |= clampi(__double2loint(c + magic), 0, 12) << (8 * j);
+                // byte j of w = min(unsigned(rounded + offset), 12) in ONE instruction (a sub-dword destination,
+                // SDWA).  The UNSIGNED minimum sends negative values to 12 where the signed clamp gave 0; both
+                // name cells that are never occupied (a padding column, an empty level outside the zone) and never
+                // in the build zone, and that is all hit_test and place / break ask of a clamped coordinate.
+                sdwa_min_into_byte(w, (uint32_t)__double2loint(c + magic), twelve, j);
                 if (r * 4 + j + 1 < SAMPLES) c = c + sc;
             }
-            const unsigned wx = (unsigned)dpp_quad<QUAD_BCAST0>(w), wy = (unsigned)dpp_quad<QUAD_BCAST1>(w),
-                           wz = (unsigned)dpp_quad<QUAD_BCAST2>(w);
+            const unsigned wx = (unsigned)dpp_quad<QUAD_BCAST0>((int)w), wy = (unsigned)dpp_quad<QUAD_BCAST1>((int)w),
+                           wz = (unsigned)dpp_quad<QUAD_BCAST2>((int)w);
             // byte gl of wx, wy, wz -> bytes 0, 1, 2 of the key
             const int key = (int)__builtin_amdgcn_perm(wz, __builtin_amdgcn_perm(wy, wx, sel_xy), sel_z);
             kidx[r] = key_idx(key);

@@ -323,18 +323,20 @@ struct Motion {  // get_motion_vector (core/world.py:163-201): constant over the
     double x, y, z;
 };
 
-// World.step (core/world.py:434-456) after action parsing, first half: movement, camera, place / break.
-// Every lane of the group runs it with identical inputs, hit_test splits its work over the lanes.  For a
-// break, ch.old_val is the pending colour load of the block that was hit: nothing here waits for it
-// (finish_break consumes it after the physics).
-template <int GS, int MODE, bool PRIO = false>
-__device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
-                                       const int8_t* grid_g, const TrigCtx& trig, double s0, double s1, double dy,
-                                       int inventory, double cam0, double cam1, bool remove, bool add, Motion& mv,
-                                       bool boost = false, uint32_t* scratch = nullptr) {
+// World.step (core/world.py:434-456) after action parsing, first half: movement, camera, place / break -- in two
+// parts with the ray march (hit_test) between them, because the march of an env need not run on its own lanes
+// (step_kernel shares the marches of a block over its wavefronts).
+struct ActPre {
+    bool want_sight, add, remove;
+    double vx, vy, vz;  // sight vector (get_sight_vector, core/world.py:312-318); only when want_sight
+};
+
+// movement, move_camera, the step's trig and the motion vector.  Every lane of the group runs it with identical
+// inputs.
+template <int GS, int MODE>
+__device__ inline ActPre world_act_pre(const Grp<GS>& G, const KParams& p, Env& e, const TrigCtx& trig, double s0, double s1,
+                                       double dy, int inventory, double cam0, double cam1, bool remove, bool add, Motion& mv) {
     constexpr bool FLY = MODE == MODE_FLY;
-    CellChange ch;
-    ch.idx = -1; ch.bit = 0; ch.old_val = 0; ch.new_val = 0;
     if (p.select_and_place && inventory != 0) { add = true; remove = false; }  // :444-446
     // movement, :344-356
     if (dy != 0.0 && e.vy == 0.0) e.vy = JUMP_SPEED * dy;
@@ -352,7 +354,10 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
     // when flying, motion vector -- one evaluation serves both, same argument => same value), yaw - 90
     // (sight vector) and yaw + strafe heading (motion vector).  They are independent, so in groups of 4+
     // lanes each is evaluated by one lane (same code, argument chosen by lane) and exchanged.
-    const bool want_sight = add != remove && !IGW_DIAG_FLAG(p, 2);
+    ActPre a;
+    a.add = add; a.remove = remove;
+    a.want_sight = add != remove && !IGW_DIAG_FLAG(p, 2);
+    const bool want_sight = a.want_sight;
     const bool strafing = s0 != 0.0 || s1 != 0.0;
     double strafe_deg = 0.0;
     if (strafing) {  // math.degrees(math.atan2(*agent.strafe)), :176
@@ -364,9 +369,9 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
     const bool want_pitch = want_sight || (FLY && strafing);
     double sp = 0.0, cp = 1.0, sy = 0.0, cy = 1.0, sx = 0.0, cx = 1.0;
     if constexpr (GS >= 4) {
-        const int a = G.gl & 3;
-        const double deg = a == 1 ? e.yaw - 90.0 : a == 2 ? e.yaw + strafe_deg : e.pitch;
-        const bool need = a == 1 ? want_sight : a == 2 ? strafing : want_pitch;
+        const int l = G.gl & 3;
+        const double deg = l == 1 ? e.yaw - 90.0 : l == 2 ? e.yaw + strafe_deg : e.pitch;
+        const bool need = l == 1 ? want_sight : l == 2 ? strafing : want_pitch;
         double sv = 0.0, cv = 1.0;
         if (need) sincos_deg(trig, deg, sv, cv);
         sp = dpp_quad<QUAD_BCAST0>(sv); cp = dpp_quad<QUAD_BCAST0>(cv);
@@ -392,12 +397,20 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
             mv.z = sx;
         }
     }
-    // place_or_remove_block, :312-332
-    if (want_sight) {
-        // m = cos(radians(y)); dy = sin(radians(y)); dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
-        const double vx = cy * cp, vy = sp, vz = sy * cp;
-        const Hit h = hit_test<GS, PRIO>(G, occ_s, e.x, e.y, e.z, vx, vy, vz, boost, scratch);
-        if (add) {
+    // m = cos(radians(y)); dy = sin(radians(y)); dx = cos(radians(x - 90)) * m; dz = sin(radians(x - 90)) * m
+    a.vx = cy * cp; a.vy = sp; a.vz = sy * cp;
+    return a;
+}
+
+// place_or_remove_block, :312-332, given the result of the ray march.  For a break, ch.old_val is the pending
+// colour load of the block that was hit: nothing here waits for it (finish_break consumes it after the physics).
+template <int GS>
+__device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* occ_s, const int8_t* grid_g, const ActPre& a,
+                                            const Hit& h) {
+    CellChange ch;
+    ch.idx = -1; ch.bit = 0; ch.old_val = 0; ch.new_val = 0;
+    if (a.want_sight) {
+        if (a.add) {
             if (h.hit && h.have_prev) {
                 if (inv_get(e.inv, e.active - 1) > 0 && build_zone_i(h.px, h.py, h.pz)) {
                     const double x = e.x, z = e.z;
@@ -415,7 +428,7 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
                 }
             }
         }
-        if (remove && h.hit && h.by != -2) {  // GREY / WHITE ground cannot be broken (:330)
+        if (a.remove && h.hit && h.by != -2) {  // GREY / WHITE ground cannot be broken (:330)
             const int cell = cell_of(h.bx, h.by, h.bz);
             // colour of the block: the one int8 the physics ever needs (L1-bypassing load: a fused
             // rollout may have written this row earlier in the same launch)
@@ -438,6 +451,20 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
         }
     }
     return ch;
+}
+
+// ... and with the march on the env's own lanes (hit_test splits its work over the lanes of the group)
+template <int GS, int MODE, bool PRIO = false>
+__device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& e, uint32_t* occ_s,
+                                       const int8_t* grid_g, const TrigCtx& trig, double s0, double s1, double dy,
+                                       int inventory, double cam0, double cam1, bool remove, bool add, Motion& mv,
+                                       bool boost = false, uint32_t* scratch = nullptr) {
+    const ActPre a = world_act_pre<GS, MODE>(G, p, e, trig, s0, s1, dy, inventory, cam0, cam1, remove, add, mv);
+    Hit h;
+    h.hit = false; h.have_prev = false;
+    h.bx = h.by = h.bz = h.px = h.py = h.pz = 0;
+    if (a.want_sight) h = hit_test<GS, PRIO>(G, occ_s, e.x, e.y, e.z, a.vx, a.vy, a.vz, boost, scratch);
+    return world_act_post<GS>(G, e, occ_s, grid_g, a, h);
 }
 
 // remove_block's inventory refund (env.py:146-153 via the on_remove callback), once the colour has arrived
@@ -530,9 +557,13 @@ __device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int,
     const int right = mi - e.max_int;
     e.max_int = mi;
     done = done || (e.step_no == p.max_steps);
-    double reward;
-    if (right == 0) reward = (double)wrong * p.wrong_scale;
-    else reward = (double)right * p.right_scale;
+    // Both scales are read as scalars first: left alone the compiler turns "one of two kernel parameters" into ONE
+    // vector load from the kernarg segment at a per-lane address -- a memory load at the end of the step whose
+    // s_waitcnt vmcnt(0) also waits for every store issued before it (observations, pose, histogram rows).
+    double rs = p.right_scale, ws = p.wrong_scale;
+    asm volatile("" : "+s"(rs), "+s"(ws));
+    const double reward_right = (double)right * rs, reward_wrong = (double)wrong * ws;
+    double reward = right == 0 ? reward_wrong : reward_right;
     if (p.size_reward) {
         const int mx = max(env_max_int, e.size);
         reward = (double)(mx - e.size);
@@ -856,7 +887,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint4 now = row[j * 16 + sub];
-                dst[j * 16 + sub] = now;
+                dst[j * 16 + sub] = now;  // (plain stores: non-temporal ones measured no better, the CDM workload worse)
                 pm = __builtin_elementwise_max(pm, __builtin_elementwise_max(
                     __builtin_elementwise_max(__builtin_bit_cast(us2, now.x), __builtin_bit_cast(us2, now.y)),
                     __builtin_elementwise_max(__builtin_bit_cast(us2, now.z), __builtin_bit_cast(us2, now.w))));
@@ -1063,10 +1094,10 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     e.step_no = min(e.step_no + 1, 65535);  // env.py:276
     CellChange ch;
     Motion mv;
+    ActPre ap;
     if (MODE == MODE_WALK) {
         const WalkAct w = parse_walking_discrete(ra.action);
-        ch = world_act<GS, MODE_WALK, true>(G, p, e, occ_s, grid_g, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1,
-                                      w.remove, w.add, mv, boost, sh.ws[wave].hist[0]);
+        ap = world_act_pre<GS, MODE_WALK>(G, p, e, trig, w.s0, w.s1, w.dy, w.inventory, w.cam0, w.cam1, w.remove, w.add, mv);
     } else if (MODE == MODE_WALK_DICT) {  // parse_walking_action, core/world.py:396-414
         const uint2 bw = ra.buttons;
         const bool fwd = bw.x & 0xffu, back = bw.x & 0xff00u, left = bw.x & 0xff0000u, right = bw.x & 0xff000000u;
@@ -1081,8 +1112,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
         if (!camera_ok(c1)) { c1 = 0.0; bad = true; }
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
         const double s0 = (fwd ? -1.0 : 0.0) + (back ? 1.0 : 0.0), s1 = (left ? -1.0 : 0.0) + (right ? 1.0 : 0.0);
-        ch = world_act<GS, MODE_WALK_DICT, true>(G, p, e, occ_s, grid_g, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1,
-                                           attack, use, mv, boost, sh.ws[wave].hist[0]);
+        ap = world_act_pre<GS, MODE_WALK_DICT>(G, p, e, trig, s0, s1, jump ? 1.0 : 0.0, hotbar, c0, c1, attack, use, mv);
     } else {  // parse_flying_action, core/world.py:416-432
         if constexpr (FLY_SPREAD) fly_fields(ra);
         const int placement = ra.placement;
@@ -1095,9 +1125,14 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
             if (i < 3 ? !__builtin_isfinite(f[i]) : !camera_ok(f[i])) { f[i] = 0.0; bad = true; }
         }
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
-        ch = world_act<GS, MODE_FLY, true>(G, p, e, occ_s, grid_g, trig, f[0], f[1], f[2], inventory, f[3], f[4],
-                                     placement == 2, placement == 1, mv, boost, sh.ws[wave].hist[0]);
+        ap = world_act_pre<GS, MODE_FLY>(G, p, e, trig, f[0], f[1], f[2], inventory, f[3], f[4], placement == 2, placement == 1, mv);
     }
+    // hit_test (core/world.py:73-99) for the envs that place or break -- 8 of the 18 walking actions.
+    Hit h;
+    h.hit = false; h.have_prev = false;
+    h.bx = h.by = h.bz = h.px = h.py = h.pz = 0;
+    if (ap.want_sight) h = hit_test<GS, true>(G, occ_s, e.x, e.y, e.z, ap.vx, ap.vy, ap.vz, boost, sh.ws[wave].hist[0]);
+    ch = world_act_post<GS>(G, e, occ_s, grid_g, ap, h);
     // issued here, consumed after the histogram update
     int start_val = 0, env_max_int = 0;
     if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
@@ -1121,7 +1156,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     asm volatile("" : "+v"(start_val), "+v"(env_max_int));
     // Pose and observations are final: their stores are issued here -- behind that wait, so it does not wait for
     // them -- and complete in the shadow of the histogram update's LDS round trips, not at the very end of the
-    // wave.  (A reset at the end of this step overwrites them: same lane, same addresses, program order.)
+    // wave (issued from tail_step instead: +0.7 % launch time, same-box A/B).  (A reset at the end of this step
+    // overwrites them: same lane, same addresses, program order.)
     if (writer) {
         if (!IGW_DIAG_FLAG(p, 16)) write_step_obs(p, env, e);
         env_store_pose(e, p.agent + env);

@@ -5,7 +5,7 @@
 # (copy those into profiles/ to commit them).
 set -u
 TAG=${1:-r02}
-ARGS=${2:-"--no-cpu-baseline --no-fused --no-async --steps 200 --warmup 20"}
+ARGS=${2:-"--no-cpu-baseline --no-fused --no-async --no-secondary --windows 3 --rehearsals 1 --steps 200 --warmup 20"}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
