@@ -133,6 +133,46 @@ __device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_si
     // agent.dy, time_int_steps, active_block are NOT reset by the reference
 }
 
+// What GridWorld.reset takes from the task's metadata row, as registers: a wavefront that knows at the START of a
+// step that one of its episodes runs out in it (step_no + 1 == max_steps, the usual end of an episode) fetches
+// these with the step's other inputs instead of at the end, where two dependent memory round trips -- each behind an
+// s_waitcnt that also waits for the step's stores -- used to make the resetting wavefront the last of its CU.
+struct ResetMeta {
+    double pose[5];
+    int target_size;
+    uint64_t inv;
+    bool has_start;
+};
+__device__ inline ResetMeta load_reset_meta(const TaskMeta* meta) {
+    ResetMeta r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.pose[i] = meta->pose[i];
+    r.target_size = meta->target_size;
+    r.has_start = meta->has_start != 0;
+    uint64_t inv = 0;  // env.py:243-246
+#pragma unroll
+    for (int i = 0; i < 6; i++) inv |= (uint64_t)(uint8_t)meta->inv_init[i] << (8 * i);
+    r.inv = inv;
+    return r;
+}
+__device__ inline void reset_env_regs(Env& e, const ResetMeta& m, bool keep_size, int generated_size = -1) {
+    if (!keep_size) e.size = 0;  // SizeReward.reset, env.py:321-323
+    e.step_no = 0;               // env.py:217
+    e.prev_size = 0;             // _synthetic_task.reset(): prev_grid_size = 0, max_int = 0 (task.py:74-86)
+    e.max_int = 0;
+    e.dirty = 0;
+    e.x = m.pose[0]; e.y = m.pose[1]; e.z = m.pose[2];  // env.py:239-240
+    e.yaw = m.pose[3]; e.pitch = m.pose[4];
+    if (generated_size >= 0) {   // the row was just written by the on-device generator: empty start, full inventory
+        e.target_size = generated_size;
+        e.inv = 0x141414141414ull;
+    } else {
+        e.target_size = m.target_size;
+        e.inv = m.inv;
+    }
+    // agent.dy, time_int_steps, active_block are NOT reset by the reference
+}
+
 // A reset counts a new episode and, with a task generator on the device, picks the env's next task row.
 // Returns the number of the episode that ends (the samplers' key).  `leader`: the one lane that stores.
 __device__ inline uint32_t next_task(const KParams& p, int env, bool leader, int& task) {
@@ -988,18 +1028,18 @@ template <int GS, int MODE, bool EXTRA>
 __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn& a, BlockShared<GS>& sh, int wave, int env,
                                  bool active, Env& e, const CellChange& ch, int task, int env_max_int, int size_new, int mi,
                                  bool need, bool changed, int8_t* grid_g, const uint32_t* occ_s, bool boost,
-                                 [[maybe_unused]] int diag_m) {
+                                 [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok) {
     const StepOut o = finish_step(p, e, env_max_int, size_new, mi);
     const bool do_reset = active && o.done && p.autoreset;
     uint32_t ep = 0;
     const int task_old = task;
     int generated_size = -1;
     bool has_start = false;
-    const TaskMeta* meta = nullptr;
     if (do_reset) {
         ep = next_task(p, env, G.gl == 0, task);  // the next episode's task (task generators on the device)
-        meta = p.task_meta + task;
-        has_start = !p.rt_enabled && meta->has_start != 0;
+        // (an episode that ends early -- target completed -- or a task that was only just chosen: fetched now)
+        if (!pre_ok) rm = load_reset_meta(p.task_meta + task);
+        has_start = !p.rt_enabled && rm.has_start;
     }
     resolve_resets<GS, EXTRA>(G, p, do_reset, env, task, has_start, ep, nullptr,
                               reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size);
@@ -1019,7 +1059,7 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
             write_trajectory<MODE>(p, a, env, task_old, ep_now, e, ch, o, do_reset, task);
         }
     }
-    if (do_reset) reset_env_regs(e, meta, false, generated_size);
+    if (do_reset) reset_env_regs(e, rm, false, generated_size);
     if (G.gl == 0) {
         if (ch.idx >= 0 && !do_reset) {
             grid_g[ch.idx] = (int8_t)ch.new_val;
@@ -1079,16 +1119,17 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     occ_commit<GS>(G, occ_in, occ_s, occ_wave_s);
     Env e;
     env_unpack(e, rec);
-    // an episode that reaches max_steps in this step is reset inside the kernel: start its task's metadata
-    // line on its way now (the reset reads it at the end; with a task generator on the next task is not known yet)
-    [[maybe_unused]] int meta_touch = 0;
-    if (p.autoreset && e.step_no + 1 >= p.max_steps && !p.sample_tasks && !p.rt_enabled)
-        meta_touch = p.task_meta[task].target_size;
+    // an episode that reaches max_steps in this step is reset inside the kernel: what the reset needs of its task's
+    // metadata row is fetched now (ResetMeta; with a task generator on the next task is not known yet)
+    const bool ends = p.autoreset && e.step_no + 1 >= p.max_steps;
+    const bool pre_ok = ends && !p.sample_tasks && !p.rt_enabled;
+    ResetMeta pre = {};
+    if (pre_ok) pre = load_reset_meta(p.task_meta + task);
     wave_sync();
     stamp(p, 1);
     if (IGW_DIAG_FLAG(p, 128)) return;  // diag 128: launch + the input burst, nothing else
     // a wave with an episode running out in this step has the reset to do on top: one priority level up
-    const bool boost = __any(p.autoreset && e.step_no + 1 >= p.max_steps);
+    const bool boost = __any(ends);
     prio_at<true, 1>(boost);
     [[maybe_unused]] const int diag_m = e.tis;  // IGW_DIAG: sub-steps this env asked for
     e.step_no = min(e.step_no + 1, 65535);  // env.py:276
@@ -1178,7 +1219,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     stamp(p, 5);
     prio_at<true, 6>(boost);
     // (KParams must stay the kernel's FIRST parameter: kernarg_again reads it at offset 0 of the kernarg segment)
-    tail_step<GS, MODE, EXTRA>(G, kernarg_again(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m);
+    tail_step<GS, MODE, EXTRA>(G, kernarg_again(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok);
 }
 
 // T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
