@@ -56,6 +56,10 @@ def cdm(n, seed, goals, device='cpu'):
     # a random fraction of every target's blocks is already there at reset
     frac = torch.rand((n, 1), generator=g)
     keep = (torch.rand((n, 1089), generator=g) < frac) & (targets != 0)
+    # ... but never all of them: a task whose target is already built is `done` at every step (tasks/task.py:107)
+    # and would reset every step; one random block of every target is always left to build
+    score = torch.rand((n, 1089), generator=g).masked_fill(targets == 0, -1.0)
+    keep[torch.arange(n), score.argmax(dim=1)] = False
     starts = torch.where(keep, targets, torch.zeros_like(targets))
     # a third of the envs: up to three foreign blocks on the lower levels, on cells the target leaves empty
     extra_env = torch.rand((n,), generator=g) < (1.0 / 3.0)

@@ -19,7 +19,11 @@ out = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/stamps.npz'
 gs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 8: stamps do not drain the memory queues
 env = VecGridWorld(N, size_reward=False, autoreset=True, lanes_per_env=gs, debug_flags=flags)
-env.set_tasks(workloads.rt20(N, seed=0, device=env.device))
+if os.environ.get('IGW_STAMP_WORKLOAD') == 'cdm':   # the real IGLU targets with partial starting grids
+    _tg, _st = workloads.cdm(N, 0, np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'cdm_goals.npz'))['dense'])
+    env.set_tasks(_tg.to(env.device), _st.to(env.device))
+else:
+    env.set_tasks(workloads.rt20(N, seed=0, device=env.device))
 env.reset()
 g = torch.Generator(device=env.device)
 g.manual_seed(1)
