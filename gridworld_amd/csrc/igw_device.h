@@ -518,15 +518,16 @@ __device__ inline void key_unpack(int key, int& x, int& y, int& z) {
     x = (key & 0xff) - 6; y = ((key >> 8) & 0xff) - 4; z = ((key >> 16) & 0xff) - 6;
 }
 
-// byte `j` of `w` := min(v, lim) (unsigned), the other bytes of w untouched: v_min_u32 with a byte destination.
+// byte `j` of `w` := min(v, lim) (unsigned), the other bytes of w untouched (j == 0: zeroed): v_min_u32 with a byte
+// destination.
 __device__ inline void sdwa_min_into_byte(uint32_t& w, uint32_t v, uint32_t lim, int j) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (j == 0) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(v), "v"(lim));
+    if (j == 0) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(w) : "v"(v), "v"(lim));  // (byte 0 starts a new word: the other bytes := 0)
     else if (j == 1) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(v), "v"(lim));
     else if (j == 2) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(v), "v"(lim));
     else asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(v), "v"(lim));
 #else
-    w = (w & ~(0xffu << (8 * j))) | ((v < lim ? v : lim) << (8 * j));
+    w = (j == 0 ? 0u : (w & ~(0xffu << (8 * j)))) | ((v < lim ? v : lim) << (8 * j));
 #endif
 }
 
@@ -567,7 +568,7 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
         const uint32_t twelve = 12u;
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
-            uint32_t w = 0;
+            uint32_t w;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // byte j of w = min(unsigned(rounded + offset), 12) in ONE instruction (a sub-dword destination,
