@@ -370,7 +370,14 @@ struct TrigCtx {
 // cos / sin of math.radians(deg).  Multiples of 5 degrees inside the table (all that discrete
 // walking can produce) come from the LUT; anything else from the build's own
 // double-precision sincos (igw_trig.h).
+// LUT = false (flying: angles are arbitrary floats, practically never on the lattice) goes straight to the general
+// evaluation, which returns the same bits on the lattice (tests/test_trig.py).
+template <bool LUT = true>
 __device__ inline void sincos_deg(const TrigCtx& t, double deg, double& s, double& c) {
+    if constexpr (!LUT) {
+        igw_sincos(deg * PI_OVER_180, &s, &c);
+        return;
+    }
     int id = (int)deg;
     if ((double)id == deg && id >= 5 * IGW_LUT_K0 && id <= 5 * (IGW_LUT_K0 + IGW_LUT_N - 1) && (id % 5) == 0) {
         int k = id / 5 - IGW_LUT_K0;

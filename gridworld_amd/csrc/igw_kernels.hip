@@ -413,14 +413,14 @@ __device__ inline ActPre world_act_pre(const Grp<GS>& G, const KParams& p, Env& 
         const double deg = l == 1 ? e.yaw - 90.0 : l == 2 ? e.yaw + strafe_deg : e.pitch;
         const bool need = l == 1 ? want_sight : l == 2 ? strafing : want_pitch;
         double sv = 0.0, cv = 1.0;
-        if (need) sincos_deg(trig, deg, sv, cv);
+        if (need) sincos_deg<!FLY>(trig, deg, sv, cv);
         sp = dpp_quad<QUAD_BCAST0>(sv); cp = dpp_quad<QUAD_BCAST0>(cv);
         sy = dpp_quad<QUAD_BCAST1>(sv); cy = dpp_quad<QUAD_BCAST1>(cv);
         sx = dpp_quad<QUAD_BCAST2>(sv); cx = dpp_quad<QUAD_BCAST2>(cv);
     } else {
-        if (want_pitch) sincos_deg(trig, e.pitch, sp, cp);
-        if (want_sight) sincos_deg(trig, e.yaw - 90.0, sy, cy);
-        if (strafing) sincos_deg(trig, e.yaw + strafe_deg, sx, cx);
+        if (want_pitch) sincos_deg<!FLY>(trig, e.pitch, sp, cp);
+        if (want_sight) sincos_deg<!FLY>(trig, e.yaw - 90.0, sy, cy);
+        if (strafing) sincos_deg<!FLY>(trig, e.yaw + strafe_deg, sx, cx);
     }
     // get_motion_vector, :163-201 (rotation and strafe are constant over the sub-steps)
     mv.x = 0.0; mv.y = 0.0; mv.z = 0.0;
