@@ -163,6 +163,15 @@ def test_input_validation_and_counters():
     assert wd.stats()['bad_actions'] == 3 and np.all(wd.internals()[:, 3:5] == 0)
     with pytest.raises(TypeError):
         VecGridWorld(n, max_step=100)          # a misspelt create_env kwarg is an error, as in the reference
+    # block ids are 0..7: Python raises, the C ABI counts the row and never matches such a cell
+    odd = tg.clone(); odd[3, 0, 5, 5] = 9
+    with pytest.raises(ValueError):
+        wd.set_tasks(odd)
+    rows9 = torch.zeros((n, L.GRID_STRIDE), dtype=torch.int8, device=wd.device)
+    rows9[:, :1089] = odd.reshape(n, -1).to(wd.device)
+    L.check(wd.lib.igw_prepare_tasks(wd.ctx, 0, n, rows9.data_ptr(), None, None, None, None, wd._stream()), 'prep')
+    torch.cuda.synchronize()
+    assert wd.stats()['bad_tasks'] == 1
     # the fused loops do not write the episode log: refused while it is enabled (C ABI: IGW_ERR_INVALID)
     w = VecGridWorld(n, autoreset=True)
     w.set_tasks(tg)
