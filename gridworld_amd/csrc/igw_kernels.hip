@@ -356,6 +356,7 @@ struct CellChange {
     // old_val: the cell's colour before the step as the RAW zero-extended byte of a (possibly still pending) load:
     // converting it where it is loaded would make the wave wait for the load there; old_colour() does it at the use
     int old_val, new_val;
+    uint32_t occ_word;  // the changed word of the occupancy row, as updated (leader lane; goes back to HBM at the end)
 };
 __device__ inline int old_colour(const CellChange& ch) { return (int)(int8_t)ch.old_val; }
 
@@ -448,7 +449,7 @@ template <int GS>
 __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* occ_s, const int8_t* grid_g, const ActPre& a,
                                             const Hit& h) {
     CellChange ch;
-    ch.idx = -1; ch.bit = 0; ch.old_val = 0; ch.new_val = 0;
+    ch.idx = -1; ch.bit = 0; ch.old_val = 0; ch.new_val = 0; ch.occ_word = 0;
     if (a.want_sight) {
         if (a.add) {
             if (h.hit && h.have_prev) {
@@ -486,6 +487,7 @@ __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* 
                 uint32_t w = occ_s[li >> 5];
                 w = ch.new_val ? (w | bit) : (w & ~bit);
                 occ_s[li >> 5] = w;
+                ch.occ_word = w;
             }
             wave_sync();
         }
@@ -597,19 +599,35 @@ __device__ inline int syn_size_delta(const CellChange& ch, int start_val) {
 }
 
 // part 2 + GridWorld.step tail (env.py:290-296) + SizeReward.step (env.py:325-331)
-__device__ inline StepOut finish_step(const KParams& p, Env& e, int env_max_int, int size_new, int mi) {
+// The kernel parameters the END of a step needs on its common path, read from the kernarg segment in ONE batch and
+// EARLY (before the physics, so that the scalar loads complete in its shadow): read where they are used they cost the
+// tail of every wavefront two or three scalar-memory round trips one after the other.
+struct TailParams {
+    int max_steps, size_reward, autoreset;
+    double right_scale, wrong_scale;
+    float* reward;
+    uint8_t* done;
+    AgentRec* agent;
+    unsigned long long* stats;
+    uint32_t* occ;
+};
+__device__ inline TailParams tail_params(const KParams& p) {
+    TailParams t = {p.max_steps, p.size_reward, p.autoreset, p.right_scale, p.wrong_scale, p.reward, p.done, p.agent, p.stats, p.occ};
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(t.max_steps), "+s"(t.size_reward), "+s"(t.autoreset), "+s"(t.right_scale), "+s"(t.wrong_scale),
+                 "+s"(t.reward), "+s"(t.done), "+s"(t.agent), "+s"(t.stats), "+s"(t.occ));
+#endif
+    return t;
+}
+
+__device__ inline StepOut finish_step(const TailParams& p, Env& e, int env_max_int, int size_new, int mi) {
     const int wrong = e.prev_size - size_new;
     bool done = mi == e.target_size;
     e.prev_size = size_new;
     const int right = mi - e.max_int;
     e.max_int = mi;
     done = done || (e.step_no == p.max_steps);
-    // Both scales are read as scalars first: left alone the compiler turns "one of two kernel parameters" into ONE
-    // vector load from the kernarg segment at a per-lane address -- a memory load at the end of the step whose
-    // s_waitcnt vmcnt(0) also waits for every store issued before it (observations, pose, histogram rows).
-    double rs = p.right_scale, ws = p.wrong_scale;
-    asm volatile("" : "+s"(rs), "+s"(ws));
-    const double reward_right = (double)right * rs, reward_wrong = (double)wrong * ws;
+    const double reward_right = (double)right * p.right_scale, reward_wrong = (double)wrong * p.wrong_scale;
     double reward = right == 0 ? reward_wrong : reward_right;
     if (p.size_reward) {
         const int mx = max(env_max_int, e.size);
@@ -1035,9 +1053,9 @@ template <int GS, int MODE, bool EXTRA>
 __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn& a, BlockShared<GS>& sh, int wave, int env,
                                  bool active, Env& e, const CellChange& ch, int task, int env_max_int, int size_new, int mi,
                                  bool need, bool changed, int8_t* grid_g, const uint32_t* occ_s, bool boost,
-                                 [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok) {
-    const StepOut o = finish_step(p, e, env_max_int, size_new, mi);
-    const bool do_reset = active && o.done && p.autoreset;
+                                 [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok, const TailParams& tp) {
+    const StepOut o = finish_step(tp, e, env_max_int, size_new, mi);
+    const bool do_reset = active && o.done && tp.autoreset;
     uint32_t ep = 0;
     const int task_old = task;
     int generated_size = -1;
@@ -1070,18 +1088,25 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
     if (G.gl == 0) {
         if (ch.idx >= 0 && !do_reset) {
             grid_g[ch.idx] = (int8_t)ch.new_val;
-            p.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = occ_s[OCC_VAR0 + (ch.bit >> 5)];
+            tp.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = ch.occ_word;
         }
         if (!IGW_DIAG_FLAG(p, 16)) {  // diag 16: what the output stores cost
-            st(p.reward + env, (float)o.reward);
-            st(p.done + env, (uint8_t)(o.done ? 1 : 0));
+            st(tp.reward + env, (float)o.reward);
+            st(tp.done + env, (uint8_t)(o.done ? 1 : 0));
             if (do_reset) write_reset_obs(p, env, e);
         }
-        if (do_reset) env_store_pose(e, p.agent + env);
-        env_store_counters(e, p.agent + env);
-        if (need) stat_add(p.stats, IGW_STAT_CHANGED, 1);
-        if (ch.idx >= 0) stat_add(p.stats, IGW_STAT_RESCANS, 1);
-        if (do_reset) stat_add(p.stats, IGW_STAT_RESETS, 1);
+        if (do_reset) env_store_pose(e, tp.agent + env);
+        env_store_counters(e, tp.agent + env);
+    }
+    {   // the wave's counters: one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
+        const uint64_t m_need = __ballot(need && G.gl == 0), m_cell = __ballot(ch.idx >= 0 && G.gl == 0),
+                       m_reset = __ballot(do_reset && G.gl == 0);
+        if ((m_need | m_cell | m_reset) != 0 && tp.stats != nullptr && G.lane == 0) {
+            unsigned long long* st = tp.stats + (blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8;
+            if (m_need) atomicAdd(st + IGW_STAT_CHANGED, (unsigned long long)__builtin_popcountll(m_need));
+            if (m_cell) atomicAdd(st + IGW_STAT_RESCANS, (unsigned long long)__builtin_popcountll(m_cell));
+            if (m_reset) atomicAdd(st + IGW_STAT_RESETS, (unsigned long long)__builtin_popcountll(m_reset));
+        }
     }
     stamp(p, 6);
 }
@@ -1190,6 +1215,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     // the histogram row, target level, start byte and bounding boxes of every changed env start moving into
     // LDS now and land while the physics runs
     const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env_r, task, ch);
+    const TailParams tp = tail_params(kernarg_again(p));
     prio_at<true, 3>(boost);
     if (MODE == MODE_FLY) world_update<GS, MODE_FLY, true>(G, p, e, occ_s, mv, boost);
     else world_update<GS, MODE_WALK, true>(G, p, e, occ_s, mv, boost);
@@ -1226,7 +1252,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     stamp(p, 5);
     prio_at<true, 6>(boost);
     // (KParams must stay the kernel's FIRST parameter: kernarg_again reads it at offset 0 of the kernarg segment)
-    tail_step<GS, MODE, EXTRA>(G, kernarg_again(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok);
+    tail_step<GS, MODE, EXTRA>(G, kernarg_again(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp);
 }
 
 // T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
@@ -1286,7 +1312,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
         // held in scalar registers over the whole loop they did not fit (121 of them parked in vector lanes)
         const KParams& p1 = kernarg_again(p);
         CellChange ch;
-        ch.idx = -1; ch.bit = 0; ch.old_val = ch.new_val = 0;
+        ch.idx = -1; ch.bit = 0; ch.old_val = ch.new_val = 0; ch.occ_word = 0;
         Motion mv = {0.0, 0.0, 0.0};
         int size_new = 0, start_val = 0;
         bool need = false;
@@ -1340,7 +1366,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
         const KParams& p3 = kernarg_again(p);
         bool do_reset = false;
         if (active) {
-            o = finish_step(p3, e, env_max_int, size_new, mi);
+            const TailParams tp3 = {p3.max_steps, p3.size_reward, p3.autoreset, p3.right_scale, p3.wrong_scale, nullptr, nullptr, nullptr, nullptr, nullptr};
+            o = finish_step(tp3, e, env_max_int, size_new, mi);
             n_changed += need;
             n_updates += changed;
             do_reset = o.done && ((MODE == MODE_WALK && io.actions == nullptr) || p3.autoreset);
