@@ -1129,6 +1129,16 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     const bool active = env < p.n_envs;
     uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The pointers the input burst needs are read from the kernarg segment in ONE batch with the batch size: left to
+    // itself the compiler reads n_envs, waits, branches, and only then reads the pointers (a second scalar round trip
+    // before the first load of the step can be issued).
+    if constexpr (GS == 4) {
+        if constexpr (MODE == MODE_WALK) asm volatile("" ::"s"(p.n_envs), "s"(p.occ), "s"(p.agent), "s"(p.env_task), "s"(a.actions));
+        else if constexpr (MODE == MODE_FLY) asm volatile("" ::"s"(p.n_envs), "s"(p.occ), "s"(p.agent), "s"(p.env_task), "s"(a.movement), "s"(a.camera), "s"(a.inventory), "s"(a.placement));
+        else asm volatile("" ::"s"(p.n_envs), "s"(p.occ), "s"(p.agent), "s"(p.env_task), "s"(a.buttons), "s"(a.camera));
+    }
+#endif
     if (wave_env0 >= p.n_envs) return;
     if (IGW_DIAG_FLAG(p, 64)) return;  // diag 64: the empty launch (same grid, registers and LDS)
     stamp(p, 0);
@@ -1148,6 +1158,22 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     RawAct ra = {};
     if constexpr (FLY_SPREAD) load_fly_spread<GS>(a, env_r, G.gl, ra);
     else ra = load_action<MODE>(a, env_r);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // ... and ONE wait: the empty statement below takes a register of every load above as an operand, and the
+    // occupancy words as in-out operands, so every load is issued before it and the LDS writes of the occupancy row
+    // come after it.  (Without it the compiler waited for the occupancy row, wrote it to LDS, and only then issued
+    // the loads of the agent record, the task index and the action: two memory round trips, 2.6 K cycles, at the head
+    // of every wavefront, in round 2 as well.)
+    if constexpr (GS == 4) {
+        uint32_t &o0 = occ_in.v[0].x, &o1 = occ_in.v[1].x, &o2 = occ_in.v[2].x;
+        if constexpr (MODE == MODE_WALK)
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.action), "v"(rec.x), "v"(rec.z), "v"(rec.pitch), "v"(rec.inv_pack));
+        else if constexpr (MODE == MODE_FLY)
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.w1), "v"(ra.w2), "v"(rec.x), "v"(rec.z), "v"(rec.pitch), "v"(rec.inv_pack));
+        else
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.buttons.x), "v"(ra.f[3]), "v"(ra.f[4]), "v"(rec.x), "v"(rec.z), "v"(rec.pitch), "v"(rec.inv_pack));
+    }
+#endif
     occ_commit<GS>(G, occ_in, occ_s, occ_wave_s);
     Env e;
     env_unpack(e, rec);
