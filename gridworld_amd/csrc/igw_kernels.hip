@@ -722,13 +722,18 @@ __device__ inline void occ_issue(const KParams& p, const Grp<GS>& G, int env, Oc
     }
 }
 template <int GS>
-__device__ inline void occ_commit(const Grp<GS>& G, const OccStage<GS>& st, uint32_t* occ_s, uint32_t* occ_wave_s) {
-    constexpr int CH = OccStage<GS>::CH, EPW = WAVE / GS;
+__device__ inline void occ_commit_var(const Grp<GS>& G, const OccStage<GS>& st, uint32_t* occ_s) {
+    constexpr int CH = OccStage<GS>::CH;
 #pragma unroll
     for (int i = 0; i < OccStage<GS>::ITER; i++) {
         const int c = G.gl + i * GS;
         if (CH % GS == 0 || c < CH) *reinterpret_cast<uint4*>(occ_s + OCC_VAR0 + 4 * c) = st.v[i];
     }
+}
+// ... the constant words of the wave's rows do not depend on any load: written while the input burst is in flight
+template <int GS>
+__device__ inline void occ_commit_const(uint32_t* occ_wave_s) {
+    constexpr int EPW = WAVE / GS;
     // constant words: 4 lanes per env, lane part q writes the 16-byte pieces q of the prefix (words 4q..4q+3)
     // and the zero words behind the variable part
     const int lane = __lane_id();
@@ -747,6 +752,11 @@ __device__ inline void occ_commit(const Grp<GS>& G, const OccStage<GS>& st, uint
             if (q < 2) *reinterpret_cast<uint4*>(row + OCC_VAR0 + OCC_WORDS + 4 * q) = make_uint4(0, 0, 0, 0);
         }
     }
+}
+template <int GS>
+__device__ inline void occ_commit(const Grp<GS>& G, const OccStage<GS>& st, uint32_t* occ_s, uint32_t* occ_wave_s) {
+    occ_commit_var<GS>(G, st, occ_s);
+    occ_commit_const<GS>(occ_wave_s);
 }
 
 // the raw action of one env, loaded before anything waits (parsed later)
@@ -1158,6 +1168,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     RawAct ra = {};
     if constexpr (FLY_SPREAD) load_fly_spread<GS>(a, env_r, G.gl, ra);
     else ra = load_action<MODE>(a, env_r);
+    occ_commit_const<GS>(occ_wave_s);   // (LDS writes that need no load: in the shadow of the burst)
 #if defined(__HIP_DEVICE_COMPILE__)
     // ... and ONE wait: the empty statement below takes a register of every load above as an operand, and the
     // occupancy words as in-out operands, so every load is issued before it and the LDS writes of the occupancy row
@@ -1174,7 +1185,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
             asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.buttons.x), "v"(ra.f[3]), "v"(ra.f[4]), "v"(rec.x), "v"(rec.z), "v"(rec.pitch), "v"(rec.inv_pack));
     }
 #endif
-    occ_commit<GS>(G, occ_in, occ_s, occ_wave_s);
+    occ_commit_var<GS>(G, occ_in, occ_s);
     Env e;
     env_unpack(e, rec);
     // an episode that reaches max_steps in this step is reset inside the kernel: what the reset needs of its task's
