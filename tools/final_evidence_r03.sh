@@ -41,4 +41,5 @@ except Exception as e:
     print(sys.argv[1], 'ERR', e, open(sys.argv[1] + '.err').read()[-1500:])
 PY
 done
+timeout 900 python3 tests/fuzz_parity.py 100 2026 > $D/fuzz_100.txt 2>&1; tail -1 $D/fuzz_100.txt
 tail -22 $D/phase_stamps_nodrain.txt | head -12; cat $D/ablation_time.txt
