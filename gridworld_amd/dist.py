@@ -141,9 +141,11 @@ def gather_counts_rccl(value, device):
         return [int(value)], 'single process'
     if device is not None and device.type == 'cuda' and 'nccl' in str(dist.get_backend_config()):
         try:
+            import datetime
             mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
             out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
-            dist.all_gather(out, mine)
+            work = dist.all_gather(out, mine, async_op=True)
+            work.wait(timeout=datetime.timedelta(seconds=float(os.environ.get('IGW_RCCL_TIMEOUT_S', '120'))))
             torch.cuda.synchronize(device)
             return [int(o.item()) for o in out], 'rccl all_gather of one int64 per rank'
         except Exception as e:  # noqa: BLE001
