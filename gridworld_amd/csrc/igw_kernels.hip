@@ -813,13 +813,9 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 #define IGW_LDS(p) ((lds_u32*)(uintptr_t)(uint32_t) reinterpret_cast<uintptr_t>(p))  /* low half of a flat LDS address = LDS offset */
 __device__ inline void glds16(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 16, 0, 0); }
 __device__ inline void glds16_sc1(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 16, 0, 16); }
-__device__ inline void glds4(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 4, 0, 0); }
-__device__ inline void glds4_sc1(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 4, 0, 16); }
 #else
 __device__ inline void glds16(const void*, uint32_t*) {}
 __device__ inline void glds16_sc1(const void*, uint32_t*) {}
-__device__ inline void glds4(const void*, uint32_t*) {}
-__device__ inline void glds4_sc1(const void*, uint32_t*) {}
 #endif
 
 // The LDS-DMA loads of one changed env into scratch slot k (whole wave): its histogram row and the colour-index
