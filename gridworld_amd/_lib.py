@@ -30,7 +30,7 @@ CAMERA_MAX = 1e6   # IGW_CAMERA_MAX
 EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',
            'igw_bind_buffers', 'igw_prepare_tasks', 'igw_set_task_sampling', 'igw_set_random_tasks',
            'igw_set_trajectory_log', 'igw_reset', 'igw_step_walking', 'igw_step_flying', 'igw_step_walking_dict',
-           'igw_rollout_walking', 'igw_rollout_walking_actions', 'igw_rollout_flying_actions', 'igw_fill_actions_walking', 'igw_task_eval']
+           'igw_rollout_walking', 'igw_rollout_walking_actions', 'igw_rollout_flying_actions', 'igw_fill_actions_walking', 'igw_task_eval', 'igw_debug_trig']
 
 
 class IgwError(RuntimeError):

@@ -1690,6 +1690,30 @@ static hipError_t upload_lut(int dev) {
     return e;
 }
 
+// Self-check of the general trig (igw_trig.h) ON THE DEVICE: the public functions' results, and whether a quick
+// evaluation accepted a value that differs from the accurate one (it never may).  tests/test_gpu_flying.py compares
+// the results with the host compile of the same header (correctly rounded on both sides).
+__global__ void debug_trig_kernel(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ sin_out,
+                                  double* __restrict__ cos_out, double* __restrict__ atan_out, uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b[i];
+    double s = 0.0, c = 0.0, qs = 0.0, qc = 0.0, as = 0.0, ac = 0.0, qa;
+    const bool in_range = __builtin_fabs(x) < 0x1p20;   // igw_sincos is specified for |x| < 2^20 (the camera bound keeps it there)
+    bool ok_sc = false;
+    if (in_range) {
+        igw_sincos(x, &s, &c);
+        ok_sc = x != 0.0 && igw_sincos_quick(x, &qs, &qc);
+        igw_sincos_accurate(x, &as, &ac);
+    }
+    const double at = igw_atan2(x, y);
+    const bool ok_at = x != 0.0 && y != 0.0 && igw_atan2_quick(x, y, &qa);
+    const double aa = (x != 0.0 && y != 0.0) ? igw_atan2_accurate(x, y) : at;
+    sin_out[i] = s; cos_out[i] = c; atan_out[i] = at;
+    flags[i] = (ok_sc ? 1 : 0) | ((ok_sc && (qs != as || qc != ac)) ? 2 : 0) | (ok_at ? 4 : 0) |
+               ((ok_at && (qa != aa || __builtin_signbit(qa) != __builtin_signbit(aa))) ? 8 : 0);
+}
+
 extern "C" {
 
 int igw_version(void) { return IGW_VERSION; }
@@ -1999,6 +2023,22 @@ int igw_fill_actions_walking(igw_ctx* ctx, int32_t* actions, int64_t n_steps, in
     hipLaunchKernelGGL(fill_actions_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, actions,
                        (long long)ctx->cfg.num_envs, (long long)n_steps, (long long)t0, (unsigned long long)seed,
                        (long long)env_offset);
+    HIP_TRY(hipGetLastError());
+    return IGW_OK;
+}
+
+int igw_debug_trig(int32_t device, int64_t n, const double* a, const double* b, double* sin_out, double* cos_out,
+                   double* atan_out, uint8_t* flags, void* stream) {
+    if (n < 0 || !a || !b || !sin_out || !cos_out || !atan_out || !flags) return fail(IGW_ERR_INVALID, "igw_debug_trig: bad argument");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1)
+        return fail(IGW_ERR_NO_DEVICE, "igw_debug_trig: no HIP device available (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= cnt) return fail(IGW_ERR_INVALID, "igw_debug_trig: device ordinal out of range");
+    if (n == 0) return IGW_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(IGW_ERR_HIP, "igw_debug_trig: hipSetDevice failed");
+    hipLaunchKernelGGL(debug_trig_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, n, a, b,
+                       sin_out, cos_out, atan_out, flags);
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }

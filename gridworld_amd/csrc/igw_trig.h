@@ -5,7 +5,8 @@
 // a host compile of this header produce identical bits (tests/test_trig.py, tests/test_gpu_flying.py).
 //
 // Method: double-double evaluation, then round.
-//   sincos: Cody-Waite reduction by pi/2 (triple-double, exact products via fma), table of
+//   sincos: Cody-Waite reduction by pi/2 (33-bit pieces in the quick evaluation, a triple-double with exact
+//           products via fma in the accurate one), table of
 //           sin/cos(j/256) in double-double, degree-9/8 Taylor tails on |d| <= 1/512 with the
 //           leading correction terms in double-double; a quick evaluation with an error bound first
 //           (Ziv's strategy), the full double-double one only when the bound straddles a rounding boundary.
@@ -82,6 +83,24 @@ IGW_HD dd_t dd_div(dd_t a, dd_t b) {
     return dd_add_d(q, q3);
 }
 
+// 1/b for the quick atan2's two quotients, which only need it to within 2^-51 (they are refined with an exact
+// remainder).  On the GPU: v_rcp_f64 (at least 20 good bits) + two Newton steps = 5 instructions, against 12 for the
+// IEEE division sequence; on the host: the division.  The two differ in the last bit or two of an INTERMEDIATE; the
+// returned atan2 is the correctly rounded one on both as long as each passes its rounding test, which is what
+// tests/test_trig.py (host) and tests/test_gpu_flying.py::test_device_trig_self_check (GPU) check.
+// b is finite, normal and far from the overflow / underflow thresholds (|float32 value| or 1 + t tj).
+IGW_HD double igw_recip(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+#else
+    return 1.0 / b;
+#endif
+}
+
 // Argument reduction shared by the two evaluations below: x = kd * pi/2 + r, |r| <= pi/4 (+ a rounding sliver),
 // r as a double-double.
 IGW_HD dd_t sincos_reduce(double x, double* kd_out) {
@@ -97,8 +116,7 @@ IGW_HD dd_t sincos_reduce(double x, double* kd_out) {
     return dd_add_d(r, -(kd * PIO2_3));
 }
 IGW_HD void sincos_quadrant(double kd, double sr, double cr, double* s_out, double* c_out) {
-    const long long k = (long long)kd;
-    const int n = (int)(((k % 4) + 4) % 4);
+    const int n = (int)kd & 3;  // |kd| < 2^20; two's complement & 3 == mod 4
     double sn, cs;
     if (n == 0) { sn = sr; cs = cr; }
     else if (n == 1) { sn = cr; cs = -sr; }
@@ -139,26 +157,35 @@ IGW_HD void igw_sincos_accurate(double x, double* s_out, double* c_out) {
     sincos_quadrant(kd, sr.hi, cr.hi, s_out, c_out);
 }
 
-// The quick evaluation (Ziv's strategy): the same reduction and table, but only the leading products exact
-// (two_prod) and everything small in plain double -- about a third of the flops -- as a value hi + lo with an
-// error bound E; the result is final when hi + (lo - E) and hi + (lo + E) round to the same double, which they do
-// except on about one argument in 2^19.  Returns false otherwise (the caller then runs the accurate evaluation).
+// The quick evaluation (Ziv's strategy): the same table, but only the leading products exact (two_prod) and
+// everything small in plain double -- about a third of the flops -- as a value hi + lo with an error bound E; the
+// result is final when hi + (lo - E) and hi + (lo + E) round to the same double, which they do except on about one
+// argument in 2^19.  Returns false otherwise (the caller then runs the accurate evaluation).
+// Reduction: pi/2 in 33-bit pieces A + B + C + CT.  For |kd| < 2^20 the products kd A, kd B, kd C are exact and so
+// is x - kd A (Cody-Waite), hence r = ((x - kd A) - kd B) - kd (C + CT) with ONE exact two_sum and the small terms in
+// plain double: |error| <= |kd| 2^-116.7.  The closing fast_two_sum needs |hi| >= |lo| (|lo| < 2^-45): arguments
+// within 2^-40 of a non-zero multiple of pi/2 are left to the accurate evaluation.  For kd == 0, r = x exactly.
+// d = r - j/256 is kept as dh + dl with dh = |r.hi| - j/256 (exact; zero or a multiple of ulp(r.hi) >= 2 |r.lo|) and
+// dl = +-r.lo, |dl| <= 2^-54: every formula below is an expansion in dl around dh that drops dl^2 (< 2^-108).
 // Error budget, absolute, |d| <= 2^-9.  Table points j >= 1 (results >= 2^-9 in magnitude): the largest plain-
 // double tail is C (sin d - d), <= 2^-29.6; it is computed with a relative error <= 5 * 2^-53 (coefficient, q,
 // three products, one sum): 2^-80.3; the five sums that contain it add <= 2^-82.6 each; the dropped series terms
-// (d^9/9!, d^8/8!) are < 2^-87.  Total < 2^-79; E = 2^-76.  j == 0 (sin x ~ x, possibly tiny): every tail scales
-// with d^3, the error is < 2^-71 |d|; E = 2^-68 |d|.  tests/test_trig.py: no wrong acceptance, and none with
-// E / 16 either.
+// (d^9/9!, d^8/8!) are < 2^-87; the reduction < 2^-96.  Total < 2^-79; E = 2^-76.  j == 0 (sin x ~ x, possibly
+// tiny): every tail scales with d^3, the error is < 2^-71 |d| + the reduction's; E = 2^-68 |d| + |kd| 2^-113.
+// tests/test_trig.py: no wrong acceptance, and none with E / 16 either.
 IGW_HD bool igw_sincos_quick(double x, double* s_out, double* c_out) {
     using namespace trigtab;
-    double kd;
-    dd_t r = sincos_reduce(x, &kd);
+    const double kd = __builtin_rint(x * TWO_OVER_PI);
+    const double r0 = x - kd * PIO2_A;
+    const dd_t rs = dd_two_sum(r0, -(kd * PIO2_B));
+    const double rlo = rs.lo - (kd * PIO2_C + kd * PIO2_CT);
+    const bool reduced = __builtin_fabs(rs.hi) >= 0x1p-40 || kd == 0.0;
+    const dd_t r = dd_fast_two_sum(rs.hi, rlo);
     const bool neg = r.hi < 0.0;
-    if (neg) r = dd_neg(r);
-    const double jd = __builtin_rint(r.hi * 256.0);
+    const double rh = __builtin_fabs(r.hi), rl = neg ? -r.lo : r.lo;
+    const double jd = __builtin_rint(rh * 256.0);
     const int j = (int)jd;
-    const dd_t d = dd_two_sum(r.hi - jd * 0.00390625, r.lo);
-    const double dh = d.hi, dl = d.lo;
+    const double dh = rh - jd * 0.00390625, dl = rl;
     const double Sh = SINCOS[j][0], Sl = SINCOS[j][1], Ch = SINCOS[j][2], Cl = SINCOS[j][3];
     const dd_t d2 = dd_two_prod(dh, dh);  // dh^2 exactly
     const double q = d2.hi;
@@ -173,24 +200,30 @@ IGW_HD bool igw_sincos_quick(double x, double* s_out, double* c_out) {
     const dd_t p1 = dd_two_prod(Ch, dh), p2 = dd_two_prod(Sh, ch);
     dd_t a = dd_fast_two_sum(Sh, p1.hi);   // |Sh| >= |Ch dh| for j >= 1; Sh == 0 for j == 0
     dd_t b = dd_fast_two_sum(a.hi, p2.hi);
-    double s_hi = b.hi;
-    double s_lo = (((Ch * ts + Cl * dh) + (Sh * tc + Sl * ch)) + ((p1.lo + p2.lo) + Sl)) + (a.lo + b.lo);
+    const double s_hi = b.hi;
+    const double s_lo = (((Ch * ts + Cl * dh) + (Sh * tc + Sl * ch)) + ((p1.lo + p2.lo) + Sl)) + (a.lo + b.lo);
     // cos(xj + d) = C + C (cos d - 1) - S sin d
     const dd_t p3 = dd_two_prod(Ch, ch), p4 = dd_two_prod(Sh, dh);
     a = dd_fast_two_sum(Ch, -p4.hi);       // Ch >= 0.7 > |Sh dh|
     b = dd_fast_two_sum(a.hi, p3.hi);
     const double c_hi = b.hi;
     const double c_lo = (((Ch * tc + Cl * ch) - (Sh * ts + Sl * dh)) + ((p3.lo - p4.lo) + Cl)) + (a.lo + b.lo);
-    if (neg) { s_hi = -s_hi; s_lo = -s_lo; }
 #ifndef IGW_QUICK_E_SCALE   // tests only: shrink E to find where the first wrong acceptance appears (the margin)
 #define IGW_QUICK_E_SCALE 1.0
 #endif
-    const double es = (j == 0 ? 0x1p-68 * dh : 0x1p-76) * IGW_QUICK_E_SCALE, ec = 0x1p-76 * IGW_QUICK_E_SCALE;
-    const double sv = s_hi + s_lo, cv = c_hi + c_lo;
-    const bool ok = (s_hi + (s_lo - es) == sv) && (s_hi + (s_lo + es) == sv) &&
-                    (c_hi + (c_lo - ec) == cv) && (c_hi + (c_lo + ec) == cv);
-    sincos_quadrant(kd, sv, cv, s_out, c_out);
-    return ok;
+    const double es = (j == 0 ? 0x1p-68 * dh + __builtin_fabs(kd) * 0x1p-113 : 0x1p-76) * IGW_QUICK_E_SCALE, ec = 0x1p-76 * IGW_QUICK_E_SCALE;
+    // the rounding test: both perturbed sums round to the same double => so does the exact value
+    const double su = s_hi + (s_lo - es), sv = s_hi + (s_lo + es);
+    const double cu = c_hi + (c_lo - ec), cv = c_hi + (c_lo + ec);
+    // quadrant n = kd mod 4:  (sin, cos) = (sr, cr), (cr, -sr), (-sr, -cr), (-cr, sr)
+    const int n = (int)kd & 3;
+    const double sr = neg ? -sv : sv;
+    double sn = (n & 1) ? cv : sr, cs = (n & 1) ? sr : cv;
+    if (n & 2) sn = -sn;
+    if ((n + 1) & 2) cs = -cs;
+    *s_out = sn;
+    *c_out = cs;
+    return reduced && su == sv && cu == cv;
 }
 
 // sin and cos of x (radians), |x| < 2^20
@@ -235,36 +268,38 @@ IGW_HD double igw_atan2_accurate(double y, double x) {
     return __builtin_copysign(a.hi, y);
 }
 
-// The quick evaluation (see igw_sincos_quick): two divisions instead of five, the leading sums exact, the rest
-// in plain double, as hi + lo with an error bound E.  Error budget, absolute, |u| <= 2^-9: the quotients t and u
-// are formed as q1 + q2 with q1 = a * RN(1/b), q2 = (exact remainder) * RN(1/b): error <= 2^-104 relative; the
-// largest plain-double tail is u^3/3 <= 2^-28.6, computed to <= 5 * 2^-53 relative: 2^-79.3; four sums containing
-// it: <= 2^-81.6 each; dropped series term u^9/9 < 2^-84.  Total < 2^-78; E = 2^-75.  For j == 0 without a
-// reflection the result is ~t and may be tiny: every tail scales with t^3, the error is < 2^-71 t; E = 2^-68 t.
+// The quick evaluation (see igw_sincos_quick): two reciprocals instead of five divisions, the leading sums exact, the
+// rest in plain double, as hi + lo with an error bound E.  Error budget, absolute, |u| <= 2^-9: the quotients t and u
+// are formed as q1 + q2 with q1 = a * rb, q2 = (remainder a - q1 b, one fma) * rb, rb = (1/b)(1 + e), |e| <= 2^-51
+// (igw_recip): q1 + q2 - a/b = (a/b - q1)(b rb - 1), <= 2^-101 relative; the largest plain-double tail is
+// u^3/3 <= 2^-28.6, computed to <= 5 * 2^-53 relative: 2^-79.3; three sums containing it: <= 2^-81.6 each; dropped
+// series term u^9/9 < 2^-84.  Total < 2^-78; E = 2^-75.  For j == 0 without a reflection the result is ~t and may be
+// tiny: every tail scales with t^3, the error is < 2^-71 t; E = 2^-68 t.
 IGW_HD bool igw_atan2_quick(double y, double x, double* out) {
     using namespace trigtab;
     const bool xneg = __builtin_signbit(x);
     const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
     const bool swap = ay > ax;
     const double num = swap ? ax : ay, den = swap ? ay : ax;
-    const double rd = 1.0 / den;
+    const double rd = igw_recip(den);
     const double t1 = num * rd;
-    const double t2 = __builtin_fma(-t1, den, num) * rd;  // the remainder is exact: t1 is within an ulp of num/den
+    const double t2 = __builtin_fma(-t1, den, num) * rd;  // remainder of a quotient that is within 2^-50 of num/den
     const dd_t t = dd_fast_two_sum(t1, t2);
     const double jd = __builtin_rint(t.hi * 256.0);
     const int j = (int)jd;
     const double tj = jd * 0.00390625;
     double uh = t.hi, ul = t.lo;
     if (j != 0) {
-        // u = un / ud:  un = (t - tj) (exact difference + t.lo), ud = 1 + t tj as a double-double
-        const dd_t un = dd_two_sum(t.hi - tj, t.lo);
+        // u = un / ud:  un = t - tj as unh + t.lo (unh exact; zero or a multiple of ulp(t.hi) >= 2 |t.lo|),
+        // ud = 1 + t tj as a double-double
+        const double unh = t.hi - tj;
         const dd_t m = dd_two_prod(t.hi, tj);
         dd_t ud = dd_fast_two_sum(1.0, m.hi);
         ud.lo += m.lo + t.lo * tj;
-        const double ru = 1.0 / ud.hi;
-        const double u1 = un.hi * ru;
-        const double u2 = ((__builtin_fma(-u1, ud.hi, un.hi) + un.lo) - u1 * ud.lo) * ru;
-        const dd_t u = dd_fast_two_sum(u1, u2);
+        const double ru = igw_recip(ud.hi);
+        const double u1 = unh * ru;
+        const double u2 = ((__builtin_fma(-u1, ud.hi, unh) + t.lo) - u1 * ud.lo) * ru;
+        const dd_t u = dd_fast_two_sum(u1, u2);  // u1 == 0 or |u1| > |u2|
         uh = u.hi; ul = u.lo;
     }
     // atan u = uh + ta:  ta = ul + uh^3 (-1/3 + w/5 - w^2/7), w = uh^2   (ul (1 - w) ~ ul: w ul < 2^-80)
@@ -273,21 +308,18 @@ IGW_HD bool igw_atan2_quick(double y, double x, double* out) {
     const double Ah = ATAN[j][0], Al = ATAN[j][1];
     dd_t a = dd_fast_two_sum(Ah, uh);  // Ah >= atan(1/256) > |u| for j >= 1; Ah == 0 for j == 0
     a.lo += Al + ta;
-    if (swap) {  // pi/2 - a
-        const dd_t s = dd_two_sum(PIO2_HI, -a.hi);
-        a = dd_t{s.hi, s.lo + (PIO2_LO - a.lo)};
-    }
-    if (xneg) {  // pi - a
-        const dd_t s = dd_two_sum(PI_HI, -a.hi);
-        a = dd_t{s.hi, s.lo + (PI_LO - a.lo)};
-    }
+    // the octant: a | pi/2 - a (swap) | pi - a (x < 0) | pi/2 + a (both) = B +- a in one sum (B == 0 or B > a)
+    const double Bh = swap ? PIO2_HI : (xneg ? PI_HI : 0.0), Bl = swap ? PIO2_LO : (xneg ? PI_LO : 0.0);
+    const bool minus = swap != xneg;
+    const dd_t s = dd_fast_two_sum(Bh, minus ? -a.hi : a.hi);
+    const double lo = s.lo + (Bl + (minus ? -a.lo : a.lo));
 #ifndef IGW_QUICK_E_SCALE
 #define IGW_QUICK_E_SCALE 1.0
 #endif
     const double e = ((j == 0 && !swap && !xneg) ? 0x1p-68 * uh : 0x1p-75) * IGW_QUICK_E_SCALE;
-    const double v = a.hi + a.lo;
+    const double u = s.hi + (lo - e), v = s.hi + (lo + e);
     *out = __builtin_copysign(v, y);
-    return (a.hi + (a.lo - e) == v) && (a.hi + (a.lo + e) == v);
+    return u == v;
 }
 
 // atan2(y, x) for finite arguments

@@ -260,6 +260,12 @@ int igw_rollout_flying_actions(igw_ctx* ctx, const float* movement, const float*
 int igw_fill_actions_walking(igw_ctx* ctx, int32_t* actions, int64_t n_steps, int64_t t0, uint64_t seed,
                              int64_t env_offset, void* stream);
 
+/* Test hook: the library's own general trig (csrc/igw_trig.h: flying mode, arbitrary poses) evaluated ON THE DEVICE for
+ * n argument pairs (device pointers): sin(a), cos(a) (0 for |a| >= 2^20, outside their domain), atan2(a, b), and flags[i] bit 0 / 2 = the quick evaluation of
+ * sincos / atan2 accepted, bit 1 / 3 = it accepted a value that differs from the accurate evaluation's (never set). */
+int igw_debug_trig(int32_t device, int64_t n, const double* a, const double* b, double* sin_out, double* cos_out,
+                   double* atan_out, uint8_t* flags, void* stream);
+
 /* Stateless Task evaluation for n (target, grid) pairs: buffers int8 [n][IGW_GRID_STRIDE];
  * full_grid / invariant may be NULL; outputs int32: max_int[n], argmax[n][3] = (dx, dz, rot),
  * target_size[n]; any output may be NULL. */

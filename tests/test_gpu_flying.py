@@ -249,3 +249,56 @@ def test_flying_rollout_over_recorded_actions_equals_stepping(gs, autoreset):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     sa, sb = a.stats(), b.stats()
     assert sa['changed'] == sb['changed'] and sa['resets'] == sb['resets'] and sa['bad_actions'] == sb['bad_actions'] == 2
+
+
+def test_device_trig_self_check():
+    """igw_debug_trig: the general sincos / atan2 evaluated on the device for 4 M arguments -- flying-mode angles, the
+    doubles around multiples of pi/2 (where the quick reduction cancels), the whole camera range, tiny and float32
+    strafe components.  (1) bit-identical to the host compile of the same header (both correctly rounded; the device's
+    atan2 uses v_rcp_f64 + Newton where the host divides, so this is a real check, not a tautology); (2) a quick
+    evaluation never accepted a value that differs from the accurate evaluation's; (3) it accepts almost always."""
+    import ctypes as C
+    import math
+    from gridworld_amd import _lib as L
+    from oracle import oracle as O
+    rng = np.random.RandomState(5)
+    n = 1 << 20
+    deg = np.concatenate([rng.uniform(-720, 720, n), rng.uniform(-90, 90, n // 2),
+                          np.float32(rng.uniform(-5, 5, n // 4)).astype(np.float64), rng.uniform(-1e-6, 1e-6, n // 8)])
+    typical = len(deg)
+    ks = np.concatenate([np.arange(-64, 65), rng.randint(-12000, 12000, 20000), rng.randint(-(1 << 19), 1 << 19, 20000)]).astype(np.float64)
+    near = ks * (math.pi / 2)
+    near = np.concatenate([near, np.nextafter(near, np.inf), np.nextafter(near, -np.inf), near * (1 + 2.0 ** -45),
+                           near * (1 - 2.0 ** -38), near + 2.0 ** -41, near - 2.0 ** -39])
+    a = np.concatenate([deg * (math.pi / 180.0), near, rng.uniform(-1e6, 1e6, n // 4) * (math.pi / 180.0),
+                        np.float32(rng.uniform(-1, 1, n)).astype(np.float64), np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1e-300])])
+    b = np.concatenate([np.float32(rng.uniform(-1, 1, len(a) - n - 6)).astype(np.float64), np.float32(rng.uniform(-1, 1, n)).astype(np.float64),
+                        np.array([1.0, -1.0, 0.0, -0.0, -0.0, 1.0])])
+    assert len(a) == len(b)
+    # a few strafe pairs with extreme float32 magnitudes
+    a[typical:typical + 4] = [1e-45, 3e38, 1e-30, -2e-38]
+    b[typical:typical + 4] = [3e38, 1e-45, -1e-30, 3e-38]
+    dev = torch.device('cuda:0')
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    s, c, at = (torch.zeros_like(ta) for _ in range(3))
+    fl = torch.zeros(len(a), dtype=torch.uint8, device=dev)
+    lib = L.load()
+    lib.igw_debug_trig.argtypes = [C.c_int32, C.c_int64] + [C.c_void_p] * 7
+    L.check(lib.igw_debug_trig(0, len(a), ta.data_ptr(), tb.data_ptr(), s.data_ptr(), c.data_ptr(), at.data_ptr(), fl.data_ptr(),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'igw_debug_trig')
+    torch.cuda.synchronize()
+    s, c, at, fl = s.cpu().numpy(), c.cpu().numpy(), at.cpu().numpy(), fl.cpu().numpy()
+    T = O.trig_host()
+    hs, hc, ha = np.zeros_like(a), np.zeros_like(a), np.zeros_like(a)
+    a_sc = np.where(np.abs(a) < 2.0 ** 20, a, 0.0)   # (the device reports 0 outside sincos' domain)
+    T.igw_host_sincos_array(a_sc.ctypes.data, hs.ctypes.data, hc.ctypes.data, len(a))
+    hs[np.abs(a) >= 2.0 ** 20] = 0.0
+    hc[np.abs(a) >= 2.0 ** 20] = 0.0
+    T.igw_host_atan2_array(a.ctypes.data, b.ctypes.data, ha.ctypes.data, len(a))
+    for name, d, h in (('sin', s, hs), ('cos', c, hc), ('atan2', at, ha)):
+        bad = np.nonzero(d.view(np.int64) != h.view(np.int64))[0]
+        assert len(bad) == 0, (name, len(bad), a[bad[:4]], b[bad[:4]], d[bad[:4]], h[bad[:4]])
+    assert not (fl & 2).any(), 'device sincos: the quick evaluation accepted a wrong rounding'
+    assert not (fl & 8).any(), 'device atan2: the quick evaluation accepted a wrong rounding'
+    assert (fl[:typical] & 1).astype(bool).mean() > 0.9999
+    assert (fl[:typical] & 4).astype(bool).mean() > 0.9999
