@@ -18,7 +18,9 @@ N = 65536
 out = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/stamps.npz'
 gs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 8: stamps do not drain the memory queues
-env = VecGridWorld(N, size_reward=False, autoreset=True, lanes_per_env=gs, debug_flags=flags)
+FLY = os.environ.get('IGW_STAMP_MODE') == 'flying'   # BASELINE configs[3]
+env = VecGridWorld(N, size_reward=False, autoreset=True, lanes_per_env=gs, debug_flags=flags,
+                   action_space='flying' if FLY else 'walking')
 if os.environ.get('IGW_STAMP_WORKLOAD') == 'cdm':   # the real IGLU targets with partial starting grids
     _tg, _st = workloads.cdm(N, 0, np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'cdm_goals.npz'))['dense'])
     env.set_tasks(_tg.to(env.device), _st.to(env.device))
@@ -30,17 +32,35 @@ g.manual_seed(1)
 sn = torch.randint(0, 250, (N,), generator=g, device=env.device, dtype=torch.int32)
 env.agent_buf[:, 48] = (sn & 0xff).to(torch.uint8)
 env.agent_buf[:, 49] = (sn >> 8).to(torch.uint8)
-env.rollout(250, seed=3)
-acts = env.fill_actions(60, seed=1)
+if FLY:
+    import ctypes
+    mvt = torch.empty((60, N, 3), device=env.device).uniform_(-1, 1, generator=g)
+    cam = torch.empty((60, N, 2), device=env.device).uniform_(-5, 5, generator=g)
+    inv = torch.randint(0, 7, (60, N), generator=g, device=env.device, dtype=torch.int32)
+    plc = torch.randint(0, 3, (60, N), generator=g, device=env.device, dtype=torch.int32)
+
+    def step(t):
+        rc = env.lib.igw_step_flying(env.ctx, ctypes.c_void_p(mvt[t].data_ptr()), ctypes.c_void_p(cam[t].data_ptr()),
+                                     ctypes.c_void_p(inv[t].data_ptr()), ctypes.c_void_p(plc[t].data_ptr()), env._stream())
+        assert rc == 0
+    for rep in range(5):   # pre-roll to the steady state: 300 steps
+        for t in range(60):
+            step(t)
+else:
+    env.rollout(250, seed=3)
+    acts = env.fill_actions(60, seed=1)
+
+    def step(t):
+        env.step_walking_ptr(acts[t])
 for t in range(20):
-    env.step_walking_ptr(acts[t])
+    step(t)
 waves = N * gs // 64
 st = torch.zeros((waves, 8), dtype=torch.int64, device=env.device)
 env.lib.igw_debug_set_stamps(env.ctx, st.data_ptr())
 acc = []
 for t in range(20, 60):
     st.zero_()
-    env.step_walking_ptr(acts[t])
+    step(t)
     torch.cuda.synchronize()
     acc.append(st.cpu().numpy().copy())
 env.lib.igw_debug_set_stamps(env.ctx, None)
