@@ -713,8 +713,8 @@ struct OccStage {
     uint4 v[ITER];
 };
 template <int GS>
-__device__ inline void occ_issue(const KParams& p, const Grp<GS>& G, int env, OccStage<GS>& st) {
-    const uint4* src = reinterpret_cast<const uint4*>(p.occ + (size_t)env * OCC_WORDS);
+__device__ inline void occ_issue(const uint32_t* occ, const Grp<GS>& G, int env, OccStage<GS>& st) {
+    const uint4* src = reinterpret_cast<const uint4*>(occ + (size_t)env * OCC_WORDS);
 #pragma unroll
     for (int i = 0; i < OccStage<GS>::ITER; i++) {
         const int c = G.gl + i * GS;
@@ -1043,14 +1043,17 @@ __device__ inline void write_trajectory(const KParams& p, const ActIn& a, int en
 // that reads them through it loads what it needs where it needs it (scalar loads from the constant cache) instead
 // of keeping everything it will need at the END of the step in scalar registers from the START (the step kernel
 // ran out of them and parked 29 in vector-register lanes: v_writelane / v_readlane are vector-ALU instructions).
+constexpr int STEP_KERNARG_HEAD = 56;   // the step kernel's seven leading pointer arguments
 #if defined(__HIP_DEVICE_COMPILE__)
+template <int OFFSET = 0>
 __device__ inline const KParams& kernarg_again(const KParams&) {
     typedef __attribute__((address_space(4))) const KParams kparams_c;
-    kparams_c* ka = (kparams_c*)__builtin_amdgcn_kernarg_segment_ptr();  // KParams is the first argument
+    kparams_c* ka = (kparams_c*)((__attribute__((address_space(4))) const char*)__builtin_amdgcn_kernarg_segment_ptr() + OFFSET);
     asm volatile("" : "+s"(ka));
     return *(const KParams*)ka;
 }
 #else
+template <int OFFSET = 0>
 __device__ inline const KParams& kernarg_again(const KParams& p) { return p; }
 #endif
 
@@ -1122,8 +1125,16 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
 // EXTRA: the RandomTasks generator and the episode log are compiled in (launched only when one of them is enabled,
 // so the plain kernel carries neither their code nor their registers).  Narrow groups pack so many envs per block
 // that LDS (one occupancy row per env) caps them at 2-3 blocks per CU anyway.
-template <int GS, int MODE, bool EXTRA>
-__global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams p, ActIn a) {
+template <int GS, int MODE, bool EXTRA, bool EXACT = false>
+__global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const uint32_t* h_occ, const AgentRec* h_agent, const int32_t* h_env_task,
+                                                                        const void* h_a0, const void* h_a1, const void* h_a2, const void* h_a3,
+                                                                        KParams p, ActIn a) {
+    // The seven leading arguments are what the input burst needs -- occupancy rows, agent records, task indices, the
+    // action buffers (walking: h_a0 = actions; Dict: buttons, camera; flying: movement, camera, inventory, placement)
+    // and, where a slot is free (h_a3, walking and Dict), the number of envs.  The library is built with
+    // -amdgpu-kernarg-preload-count=7: they arrive in scalar registers with the wavefront, and the first loads of the
+    // step are issued without the scalar-load round trip to the kernarg segment (-0.37 us per launch, same-box A/B).
+    // Flying has no free slot: EXACT = the batch is a whole number of blocks (no inactive lanes, no bound to read).
     __shared__ BlockShared<GS> sh;
     const Grp<GS> G;
     TrigCtx trig;
@@ -1132,38 +1143,32 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     const int slot = threadIdx.x / GS;
     const int env = blockIdx.x * BlockShared<GS>::EPB + slot;
     const int wave_env0 = blockIdx.x * BlockShared<GS>::EPB + wave * BlockShared<GS>::EPW;
-    const bool active = env < p.n_envs;
+    static_assert(!EXACT || MODE == MODE_FLY, "EXACT is the flying kernel's variant");
+    const int n_envs = MODE != MODE_FLY ? (int)(uintptr_t)h_a3 : EXACT ? 0x7fffffff : p.n_envs;
+    const bool active = EXACT || env < n_envs;
     uint32_t* occ_wave_s = sh.occ + wave * BlockShared<GS>::EPW * OCC_PITCH;
     uint32_t* occ_s = sh.occ + slot * OCC_PITCH;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // The pointers the input burst needs are read from the kernarg segment in ONE batch with the batch size: left to
-    // itself the compiler reads n_envs, waits, branches, and only then reads the pointers (a second scalar round trip
-    // before the first load of the step can be issued).
-    if constexpr (GS == 4) {
-        if constexpr (MODE == MODE_WALK) asm volatile("" ::"s"(p.n_envs), "s"(p.occ), "s"(p.agent), "s"(p.env_task), "s"(a.actions));
-        else if constexpr (MODE == MODE_FLY) asm volatile("" ::"s"(p.n_envs), "s"(p.occ), "s"(p.agent), "s"(p.env_task), "s"(a.movement), "s"(a.camera), "s"(a.inventory), "s"(a.placement));
-        else asm volatile("" ::"s"(p.n_envs), "s"(p.occ), "s"(p.agent), "s"(p.env_task), "s"(a.buttons), "s"(a.camera));
-    }
-#endif
-    if (wave_env0 >= p.n_envs) return;
+    if (!EXACT && wave_env0 >= n_envs) return;
     if (IGW_DIAG_FLAG(p, 64)) return;  // diag 64: the empty launch (same grid, registers and LDS)
     stamp(p, 0);
     prio_at<true, 0>();
     // Lanes past the last env (only in the last wave, when N is not a multiple of the envs per wave) run on a copy
     // of the last env and store nothing: the step below has no "is this lane alive" control flow.
-    const int env_r = active ? env : p.n_envs - 1;
+    const int env_r = active ? env : n_envs - 1;
     const bool writer = active && G.gl == 0;
     // Every load the step needs before it can compute -- occupancy row, agent record, task index, action -- is
     // issued before the first wait: one memory round trip.
     OccStage<GS> occ_in = {};
-    if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(p, G, env_r, occ_in);  // diag 32: what the occupancy rows cost in the load burst
-    int8_t* grid_g = p.grid + (size_t)env_r * STRIDE;
-    int task = p.env_task[env_r];
-    const AgentRec rec = p.agent[env_r];  // every lane of the group reads the same 64 B line (one request)
+    if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);  // diag 32: what the occupancy rows cost in the load burst
+    int task = h_env_task[env_r];
+    const AgentRec rec = h_agent[env_r];  // every lane of the group reads the same 64 B line (one request)
     constexpr bool FLY_SPREAD = MODE == MODE_FLY && GS >= 4;
+    const ActIn ah = {(const int32_t*)h_a0, (const float*)h_a0, (const float*)h_a1, (const int32_t*)h_a2, (const int32_t*)h_a3,
+                      (const uint8_t*)h_a0};   // (the fields of the mode's own action space are the valid ones)
     RawAct ra = {};
-    if constexpr (FLY_SPREAD) load_fly_spread<GS>(a, env_r, G.gl, ra);
-    else ra = load_action<MODE>(a, env_r);
+    if constexpr (FLY_SPREAD) load_fly_spread<GS>(ah, env_r, G.gl, ra);
+    else ra = load_action<MODE>(ah, env_r);
+    int8_t* grid_g = p.grid + (size_t)env_r * STRIDE;
     occ_commit_const<GS>(occ_wave_s);   // (LDS writes that need no load: in the shadow of the burst)
 #if defined(__HIP_DEVICE_COMPILE__)
     // ... and ONE wait: the empty statement below takes a register of every load above as an operand, and the
@@ -1248,7 +1253,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     // the histogram row, target level, start byte and bounding boxes of every changed env start moving into
     // LDS now and land while the physics runs
     const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env_r, task, ch);
-    const TailParams tp = tail_params(kernarg_again(p));
+    const TailParams tp = tail_params(kernarg_again<STEP_KERNARG_HEAD>(p));
     prio_at<true, 3>(boost);
     if (MODE == MODE_FLY) world_update<GS, MODE_FLY, true>(G, p, e, occ_s, mv, boost);
     else world_update<GS, MODE_WALK, true>(G, p, e, occ_s, mv, boost);
@@ -1284,8 +1289,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(KParams 
     }
     stamp(p, 5);
     prio_at<true, 6>(boost);
-    // (KParams must stay the kernel's FIRST parameter: kernarg_again reads it at offset 0 of the kernarg segment)
-    tail_step<GS, MODE, EXTRA>(G, kernarg_again(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp);
+    // (KParams sits behind the preloaded head arguments: kernarg_again reads it at that offset of the kernarg segment)
+    tail_step<GS, MODE, EXTRA>(G, kernarg_again<STEP_KERNARG_HEAD>(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp);
 }
 
 // T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
@@ -1320,7 +1325,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
     if (wave_env0 >= p.n_envs) return;
     {
         OccStage<GS> st;
-        occ_issue<GS>(p, G, active ? env : p.n_envs - 1, st);
+        occ_issue<GS>(p.occ, G, active ? env : p.n_envs - 1, st);
         occ_commit<GS>(G, st, occ_s, occ_wave_s);
     }
     Env e = {};
@@ -1901,15 +1906,18 @@ int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
         default: { constexpr int GS = 1; CALL; } break;  \
     }
 
-// the step kernel with or without the rarely used extras (RandomTasks generator, episode log)
-#define LAUNCH_STEP(MODE)                                                                                          \
+// the step kernel with or without the rarely used extras (RandomTasks generator, episode log); A0..A3 = the leading
+// action-buffer arguments of the mode (see step_kernel)
+#define LAUNCH_STEP(MODE, A0, A1, A2, A3)                                                                          \
     do {                                                                                                           \
         if (ctx->kp.rt_enabled || ctx->kp.traj) {                                                                  \
             DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE, true>), dim3(env_blocks(ctx)), dim3(BLOCK), 0, \
-                                                    (hipStream_t)stream, ctx->kp, a));                             \
+                                                    (hipStream_t)stream, ctx->kp.occ, ctx->kp.agent, ctx->kp.env_task,      \
+                                                    (const void*)(A0), (const void*)(A1), (const void*)(A2), (const void*)(A3), ctx->kp, a)); \
         } else {                                                                                                   \
             DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE, false>), dim3(env_blocks(ctx)), dim3(BLOCK), 0, \
-                                                    (hipStream_t)stream, ctx->kp, a));                             \
+                                                    (hipStream_t)stream, ctx->kp.occ, ctx->kp.agent, ctx->kp.env_task,      \
+                                                    (const void*)(A0), (const void*)(A1), (const void*)(A2), (const void*)(A3), ctx->kp, a)); \
         }                                                                                                          \
     } while (0)
 
@@ -1945,7 +1953,7 @@ int igw_step_walking(igw_ctx* ctx, const int32_t* actions, void* stream) {
     if (ctx->cfg.action_space != IGW_WALKING_DISCRETE) return fail(IGW_ERR_INVALID, "igw_step_walking: context was created for another action space");
     if (!actions) return fail(IGW_ERR_INVALID, "igw_step_walking: actions is null");
     ActIn a = {actions, nullptr, nullptr, nullptr, nullptr, nullptr};
-    LAUNCH_STEP(MODE_WALK);
+    LAUNCH_STEP(MODE_WALK, actions, nullptr, nullptr, (uintptr_t)ctx->kp.n_envs);
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1956,7 +1964,13 @@ int igw_step_flying(igw_ctx* ctx, const float* movement, const float* camera, co
     if (ctx->cfg.action_space != IGW_FLYING) return fail(IGW_ERR_INVALID, "igw_step_flying: context was created for another action space");
     if (!movement || !camera || !inventory || !placement) return fail(IGW_ERR_INVALID, "igw_step_flying: an action buffer is null");
     ActIn a = {nullptr, movement, camera, inventory, placement, nullptr};
-    LAUNCH_STEP(MODE_FLY);
+    if (ctx->gs == 4 && !ctx->kp.rt_enabled && !ctx->kp.traj && ctx->kp.n_envs % (BLOCK / 4) == 0) {  // whole blocks: the EXACT variant
+        hipLaunchKernelGGL((step_kernel<4, MODE_FLY, false, true>), dim3(env_blocks(ctx)), dim3(BLOCK), 0, (hipStream_t)stream, ctx->kp.occ,
+                           ctx->kp.agent, ctx->kp.env_task, (const void*)movement, (const void*)camera, (const void*)inventory,
+                           (const void*)placement, ctx->kp, a);
+    } else {
+        LAUNCH_STEP(MODE_FLY, movement, camera, inventory, placement);
+    }
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
@@ -1967,7 +1981,7 @@ int igw_step_walking_dict(igw_ctx* ctx, const uint8_t* buttons, const float* cam
     if (!buttons || !camera) return fail(IGW_ERR_INVALID, "igw_step_walking_dict: an action buffer is null");
     if ((uintptr_t)buttons & 7) return fail(IGW_ERR_INVALID, "igw_step_walking_dict: buttons must be 8-byte aligned");
     ActIn a = {nullptr, nullptr, camera, nullptr, nullptr, buttons};
-    LAUNCH_STEP(MODE_WALK_DICT);
+    LAUNCH_STEP(MODE_WALK_DICT, buttons, camera, nullptr, (uintptr_t)ctx->kp.n_envs);
     HIP_TRY(hipGetLastError());
     return IGW_OK;
 }
