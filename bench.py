@@ -513,7 +513,10 @@ def roofline_of(r, m, lanes, has_start_frac=0.0):
         hbm_bytes = hbm_bytes * N / prof_envs   # the committed profile is of the 65,536-env launch
     roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': hbm_bytes,
-            'kernel': 'igw::step_kernel<%d, %d, false>' % (lanes, 1 if flying else 0), 'kernel_avg_ms': kernel_ms,
+            # <lanes per env, action space, extras, flying's whole-blocks variant> (csrc/igw_kernels.hip)
+            'kernel': 'igw::step_kernel<%d, %d, false, %s>' % (lanes, 1 if flying else 0,
+                                                              'true' if flying and lanes == 4 and N % 64 == 0 else 'false'),
+            'kernel_avg_ms': kernel_ms,
             'algorithmic_bytes_per_env_step': bytes_per_step,
             'algorithmic_bytes_per_launch': N * bytes_per_step,
             # the same kernel time against what this design must move: the kernel is NOT HBM-bound

@@ -18,6 +18,7 @@ timeout 300 python3 tools/stamp_phases.py $D/stamps_nodrain.npz 4 8 > $D/phase_s
 timeout 300 python3 tools/stamp_phases.py $D/stamps.npz 4 > $D/phase_stamps.txt 2>&1
 FLAGS="0 16 32 1 2 4 7 256 128 64" bash tools/ablate_time.sh 2>/dev/null | grep "^flags" > $D/ablation_time.txt
 rm -f $D/*.npz
+rm -rf gpurun_out/prof_r03 gpurun_out/prof_r03_flying   # raw counter dumps: tens of MB; the summaries are in gpurun_out/profiles_r03*
 for f in bench_driver bench bench_flying bench_cdm bench_524288 bench_2ranks_shared_gpu; do
   python3 - $D/$f <<'PY'
 import json, sys
