@@ -350,6 +350,37 @@ __device__ inline void write_step_obs(const KParams& p, int env, const Env& e) {
     st(p.compass + env, (float)(e.yaw - 180.0));
 }
 
+// The same observation / pose stores by the FOUR lanes of an env's (first) quad: the CU's address pipe takes a
+// wavefront's store in 4 (dword) or 16 (dwordx4) cycles whether one lane of a quad is active or all four, so twelve
+// dword stores by the leader lane cost four times what three stores by all four lanes cost, and sixteen wavefronts
+// per CU queue there at the end of a launch.  Lane q: agent_pos[q] | agent_pos[4], compass, inventory[0], [1] |
+// inventory[2 + q].  Reset observations go the same way (same lane -> same address, so program order holds).
+__device__ __forceinline__ void store_obs_spread(const KParams& p, int env, int q, float a0, float a1, float a2, float a3, float a4,
+                                        float compass, const Env& e) {
+    float* ap = p.agent_pos + 5 * (size_t)env;
+    float* iv = p.inventory + 6 * (size_t)env;
+    const float i0 = (float)inv_get(e.inv, 0), i1 = (float)inv_get(e.inv, 1), i2 = (float)inv_get(e.inv, 2),
+                i3 = (float)inv_get(e.inv, 3), i4 = (float)inv_get(e.inv, 4), i5 = (float)inv_get(e.inv, 5);
+    st(ap + q, q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : a3);
+    float* pb = q == 0 ? ap + 4 : q == 1 ? p.compass + env : iv + (q - 2);
+    st(pb, q == 0 ? a4 : q == 1 ? compass : q == 2 ? i0 : i1);
+    st(iv + 2 + q, q == 0 ? i2 : q == 1 ? i3 : q == 2 ? i4 : i5);
+}
+__device__ __forceinline__ void write_step_obs_spread(const KParams& p, int env, int q, const Env& e) {
+    store_obs_spread(p, env, q, (float)e.x, (float)e.y, (float)e.z, (float)e.pitch, (float)e.yaw, (float)(e.yaw - 180.0), e);
+}
+__device__ __forceinline__ void write_reset_obs_spread(const KParams& p, int env, int q, const Env& e) {
+    store_obs_spread(p, env, q, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, e);
+}
+// pose: lane q < 3 stores the 16-byte piece q of the record
+__device__ __forceinline__ void env_store_pose_spread(double x, double y, double z, double yaw, double pitch, double vy, AgentRec* rec,
+                                                      int q) {
+    // (by value: a select between FIELDS of the env struct becomes a load from a selected address and parks the
+    // struct in scratch memory)
+    const double a = q == 0 ? x : q == 1 ? z : pitch, b = q == 0 ? y : q == 1 ? yaw : vy;
+    st(reinterpret_cast<vd2*>(rec) + q, vd2{a, b});
+}
+
 struct CellChange {
     int idx;  // dense cell index; -1: grid unchanged this step
     int bit;  // the cell's bit in the HBM occupancy row
@@ -1102,10 +1133,16 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
         if (!IGW_DIAG_FLAG(p, 16)) {  // diag 16: what the output stores cost
             st(tp.reward + env, (float)o.reward);
             st(tp.done + env, (uint8_t)(o.done ? 1 : 0));
-            if (do_reset) write_reset_obs(p, env, e);
+            if (GS < 4 && do_reset) write_reset_obs(p, env, e);
         }
-        if (do_reset) env_store_pose(e, tp.agent + env);
+        if (GS < 4 && do_reset) env_store_pose(e, tp.agent + env);
         env_store_counters(e, tp.agent + env);
+    }
+    if constexpr (GS >= 4) {  // the reset's observations and pose go the way the step's went (lane -> address)
+        if (do_reset && G.gl < 4) {
+            if (!IGW_DIAG_FLAG(p, 16)) write_reset_obs_spread(p, env, G.gl, e);
+            if (G.gl < 3) env_store_pose_spread(e.x, e.y, e.z, e.yaw, e.pitch, e.vy, tp.agent + env, G.gl);
+        }
     }
     {   // the wave's counters: one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
         const uint64_t m_need = __ballot(need && G.gl == 0), m_cell = __ballot(ch.idx >= 0 && G.gl == 0),
@@ -1161,7 +1198,16 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     OccStage<GS> occ_in = {};
     if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);  // diag 32: what the occupancy rows cost in the load burst
     int task = h_env_task[env_r];
-    const AgentRec rec = h_agent[env_r];  // every lane of the group reads the same 64 B line (one request)
+    // The agent record: with four or more lanes per env, lane q of a quad fetches the 16-byte piece q and the quad
+    // hands the pieces round by DPP after the wait -- ONE dwordx4 per lane instead of four.  (All four lanes reading
+    // the whole record is one cache line per env either way, but the CU's address pipe handles a wavefront's
+    // dwordx4 in 16 cycles whatever the addresses, and sixteen wavefronts per CU queue up behind one another there:
+    // the input burst of a wavefront was 48 + 64 + 8 of those cycles, the record more than half of it.)
+    constexpr bool REC_SPREAD = GS >= 4;
+    AgentRec rec;
+    uint4 rec_piece = make_uint4(0, 0, 0, 0);
+    if constexpr (REC_SPREAD) rec_piece = reinterpret_cast<const uint4*>(h_agent + env_r)[G.gl & 3];
+    else rec = h_agent[env_r];  // every lane of the group reads the same 64 B line (one request)
     constexpr bool FLY_SPREAD = MODE == MODE_FLY && GS >= 4;
     const ActIn ah = {(const int32_t*)h_a0, (const float*)h_a0, (const float*)h_a1, (const int32_t*)h_a2, (const int32_t*)h_a3,
                       (const uint8_t*)h_a0};   // (the fields of the mode's own action space are the valid ones)
@@ -1179,14 +1225,27 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     if constexpr (GS == 4) {
         uint32_t &o0 = occ_in.v[0].x, &o1 = occ_in.v[1].x, &o2 = occ_in.v[2].x;
         if constexpr (MODE == MODE_WALK)
-            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.action), "v"(rec.x), "v"(rec.z), "v"(rec.pitch), "v"(rec.inv_pack));
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.action), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
         else if constexpr (MODE == MODE_FLY)
-            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.w1), "v"(ra.w2), "v"(rec.x), "v"(rec.z), "v"(rec.pitch), "v"(rec.inv_pack));
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.w1), "v"(ra.w2), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
         else
-            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.buttons.x), "v"(ra.f[3]), "v"(ra.f[4]), "v"(rec.x), "v"(rec.z), "v"(rec.pitch), "v"(rec.inv_pack));
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.buttons.x), "v"(ra.f[3]), "v"(ra.f[4]), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
     }
 #endif
     occ_commit_var<GS>(G, occ_in, occ_s);
+    if constexpr (REC_SPREAD) {  // piece 0: x, y | 1: z, yaw | 2: pitch, vy | 3: counters, inv_pack (include/igw.h)
+        uint32_t w[16];
+        const int px = (int)rec_piece.x, py = (int)rec_piece.y, pz = (int)rec_piece.z, pw = (int)rec_piece.w;
+        w[0] = (uint32_t)dpp_quad<QUAD_BCAST0>(px); w[1] = (uint32_t)dpp_quad<QUAD_BCAST0>(py);
+        w[2] = (uint32_t)dpp_quad<QUAD_BCAST0>(pz); w[3] = (uint32_t)dpp_quad<QUAD_BCAST0>(pw);
+        w[4] = (uint32_t)dpp_quad<QUAD_BCAST1>(px); w[5] = (uint32_t)dpp_quad<QUAD_BCAST1>(py);
+        w[6] = (uint32_t)dpp_quad<QUAD_BCAST1>(pz); w[7] = (uint32_t)dpp_quad<QUAD_BCAST1>(pw);
+        w[8] = (uint32_t)dpp_quad<QUAD_BCAST2>(px); w[9] = (uint32_t)dpp_quad<QUAD_BCAST2>(py);
+        w[10] = (uint32_t)dpp_quad<QUAD_BCAST2>(pz); w[11] = (uint32_t)dpp_quad<QUAD_BCAST2>(pw);
+        w[12] = (uint32_t)dpp_quad<QUAD_BCAST3>(px); w[13] = (uint32_t)dpp_quad<QUAD_BCAST3>(py);
+        w[14] = (uint32_t)dpp_quad<QUAD_BCAST3>(pz); w[15] = (uint32_t)dpp_quad<QUAD_BCAST3>(pw);
+        __builtin_memcpy(&rec, w, sizeof(rec));
+    }
     Env e;
     env_unpack(e, rec);
     // an episode that reaches max_steps in this step is reset inside the kernel: what the reset needs of its task's
@@ -1270,7 +1329,12 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // them -- and complete in the shadow of the histogram update's LDS round trips, not at the very end of the
     // wave (issued from tail_step instead: +0.7 % launch time, same-box A/B).  (A reset at the end of this step
     // overwrites them: same lane, same addresses, program order.)
-    if (writer) {
+    if constexpr (GS >= 4) {
+        if (active && G.gl < 4) {
+            if (!IGW_DIAG_FLAG(p, 16)) write_step_obs_spread(p, env, G.gl, e);
+            if (G.gl < 3) env_store_pose_spread(e.x, e.y, e.z, e.yaw, e.pitch, e.vy, p.agent + env, G.gl);
+        }
+    } else if (writer) {
         if (!IGW_DIAG_FLAG(p, 16)) write_step_obs(p, env, e);
         env_store_pose(e, p.agent + env);
     }
