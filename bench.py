@@ -378,7 +378,7 @@ class Runner:
         # eager launches while the host is still busy launching the graph (the first launch after a synchronize takes
         # ~15 us of host time, an event record ~7, a graph launch ~20; a kernel ~14): with a head of 2 the GPU ran out
         # of work for ~15 us before the graph arrived
-        head = min(6, K - 2)
+        head = min(int(os.environ.get('IGW_BENCH_HEAD', 6)), K - 2)   # (IGW_BENCH_HEAD: experiments only)
         try:
             graph = torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream(device=self.device)
