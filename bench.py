@@ -79,6 +79,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-async', action='store_true', help='skip the secondary two-sub-batch measurement')
     ap.add_argument('--no-secondary', action='store_true', help='skip the flying / cdm secondary windows of the default run')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of one HIP-graph replay')
+    ap.add_argument('--no-api', action='store_true', help='skip the public-API loop measurements (config.api_*)')
     ap.add_argument('--lockstep', action='store_true',
                     help='skip the episode de-synchronisation (round-1 behaviour: all envs at the same episode step)')
     ap.add_argument('--mode', choices=['walking', 'flying'], default='walking',
@@ -100,12 +101,20 @@ def _free_port():
     return p
 
 
+def usable_cpus():
+    """CPUs this process can really run on at once: the affinity mask capped by the cgroup's CFS quota (the GPU
+    boxes show 256 CPUs in the mask and grant 16)."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = cgroup_cpu_quota()
+    return int(max(1, min(affinity, int(quota + 0.999) if quota else affinity)))
+
+
 def self_launch(args):
     """--gpus N > 1 outside torchrun: become the launcher.  This process never touches the GPU; the N
     ranks are children of torch.distributed.run and rank 0's JSON line is relayed to our stdout."""
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // args.gpus)))
     rc = 1
     for attempt in range(3):  # the probed port can be taken before the rendezvous binds it
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
@@ -120,10 +129,10 @@ def self_launch(args):
             else:
                 sys.stderr.write(line)
         rc = proc.wait()
-        if rc == 0 and got:
-            return 0
         if got:
-            break
+            if rc != 0:   # the result is out; a rank that aborted while tearing down afterwards does not unmake it
+                sys.stderr.write(f'bench.py: launcher exit code {rc} after the result line was relayed (teardown); reporting success\n')
+            return 0
     return rc or 1
 
 
@@ -174,8 +183,7 @@ def cpu_baseline(seed):
     from oracle import oracle as O
     affinity = len(os.sched_getaffinity(0))
     quota = cgroup_cpu_quota()
-    # threads actually used: no more than the cgroup lets run at once
-    cores = int(max(1, min(affinity, int(quota + 0.999) if quota else affinity)))
+    cores = usable_cpus()   # threads actually used: no more than the cgroup lets run at once
 
     def timed(batch, fn, T, nthreads):
         t = time.perf_counter()
@@ -252,24 +260,48 @@ def auto_lanes(n):
 
 
 def dry_run(args):
-    """No GPU: proves the launcher brought up `world` ranks that can rendezvous and reduce."""
+    """No GPU: proves the launcher brought up `world` ranks that can rendezvous, meet in the shared-memory barrier of
+    the timing bracket, reduce the windows and gather the per-rank values -- everything of a multi-rank run but the
+    kernels."""
     from gridworld_amd import dist as gdist
     rank, local_rank, world = gdist.init(backend='gloo')
-    gdist.barrier()
-    nb = gdist.NodeBarrier()  # the barrier of the timing bracket
-    for _ in range(3):
-        nb.wait()
-    total, mx = gdist.reduce_window(args.envs_per_gpu * args.steps, 1e-3 * (rank + 1))
-    wins = gdist.reduce_windows([1e-3 * (rank + 1), 2e-3 * (world - rank)])
-    ranks = gdist.gather_counts(rank)
-    if rank == 0:
-        print(json.dumps({'metric': 'dry-run', 'n_gpus': world, 'ranks': ranks, 'total_steps': total,
-                          'max_elapsed': mx, 'windows_max': wins, 'steps': args.steps, 'warmup': args.warmup}))
+    try:
+        gdist.barrier()
+        nb = gdist.NodeBarrier()  # the barrier of the timing bracket
+        for _ in range(50):
+            nb.wait()
+        total, mx = gdist.reduce_window(args.envs_per_gpu * args.steps, 1e-3 * (rank + 1))
+        wins = gdist.reduce_windows([1e-3 * (rank + 1), 2e-3 * (world - rank)])
+        ranks = gdist.gather_counts(rank)
+        kernel_us = gdist.gather_floats(10.0 + rank)
+        if rank == 0:
+            print(json.dumps({'metric': 'dry-run', 'n_gpus': world, 'ranks': ranks, 'total_steps': total,
+                              'max_elapsed': mx, 'windows_max': wins, 'steps': args.steps, 'warmup': args.warmup,
+                              'config': {'ranks_seen': ranks, 'kernel_us_per_rank': kernel_us,
+                                         'usable_cpus': usable_cpus(), 'torch_threads': _torch_threads()}}), flush=True)
+    finally:
+        gdist.shutdown()
+
+
+def _torch_threads():
+    import torch
+    return torch.get_num_threads()
+
+
+def spin_until(pred, spins=2000):
+    """Busy-wait on `pred` for a few microseconds, then yield the CPU between polls: with 8 ranks on a 16-CPU quota
+    next to RCCL proxy and watchdog threads an unbounded spin can starve the thread it is waiting for."""
+    n = 0
+    while not pred():
+        n += 1
+        if n > spins:
+            time.sleep(0) if n < 20 * spins else time.sleep(50e-6)
 
 
 class Runner:
-    """One workload on this rank's GPU: env, tasks, the W + K action buffers (refilled in place before every pass),
-    the captured graph and the contract's window."""
+    """One workload on this rank's GPU through the PUBLIC API (gridworld_amd.VecGridWorld): env, tasks, the W + K
+    action buffers (refilled in place before every pass), the captured step graph (VecGridWorld.capture_steps) and
+    the contract's window."""
 
     def __init__(self, args, mode, workload, device, rank, world, node_barrier, N=None):
         import torch
@@ -294,61 +326,42 @@ class Runner:
         self.g = g = torch.Generator(device=device)
         g.manual_seed(args.seed + 7919 * rank + (1 if self.flying else 0))
         if not args.lockstep:
-            # every env starts at a random step of its episode (GridWorld.step_no, agent record bytes 48..49)
-            sn = torch.randint(0, MAX_STEPS, (N,), generator=g, device=device, dtype=torch.int32)
-            env.agent_buf[:, 48] = (sn & 0xff).to(torch.uint8)
-            env.agent_buf[:, 49] = (sn >> 8).to(torch.uint8)
+            # every env starts at a random step of its episode (GridWorld.step_no)
+            env.set_step_no(torch.randint(0, MAX_STEPS, (N,), generator=g, device=device, dtype=torch.int32))
         self.pre_rolled = 0
         self.passes = 0
         W, K = self.W, self.K
         if self.flying:
-            self.acts = (torch.empty((W + K, N, 3), device=device), torch.empty((W + K, N, 2), device=device),
-                         torch.empty((W + K, N), device=device, dtype=torch.int32),
-                         torch.empty((W + K, N), device=device, dtype=torch.int32))
-            self.refill()
-            # the timed loop passes pre-computed device pointers: slicing a tensor per step costs more host time
-            # than the launch itself
-            self.ptrs = [tuple(a[t].data_ptr() for a in self.acts) for t in range(W + K)]
-            self._fn = env.lib.igw_step_flying
+            self.acts = dict(movement=torch.empty((W + K, N, 3), device=device), camera=torch.empty((W + K, N, 2), device=device),
+                             inventory=torch.empty((W + K, N), device=device, dtype=torch.int32),
+                             placement=torch.empty((W + K, N), device=device, dtype=torch.int32))
+            # what env.step() is handed per step: the slicing is done once (a user loop would write acts[t] inline)
+            self.act_t = [{k: v[t] for k, v in self.acts.items()} for t in range(W + K)]
         else:
-            chunk = 256
-            self.actions = [torch.empty((min(chunk, W + K - t0), N), dtype=torch.int32, device=device)
-                            for t0 in range(0, W + K, chunk)]
-            self.refill()
-            self.ptrs = [self.actions[t // chunk][t % chunk].data_ptr() for t in range(W + K)]
-            self._fn = env.lib.igw_step_walking
-        self._ctx = env.ctx
+            self.acts = torch.empty((W + K, N), dtype=torch.int32, device=device)
+            self.act_t = list(self.acts.unbind(0))
+        self.refill()
         if not args.lockstep:
             self.busy(0.0, MAX_STEPS)  # at least one episode length
-        self.graph, self.head, self.timed_as = None, K, 'eager launches'
+        self.graph, self.head, self.timed_as = None, K, 'eager env.step() calls'
         if not args.no_graph and K > 8:
             self._capture()
         self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.cur_h = env._stream()
 
     # -- actions ----------------------------------------------------------------------------------------------
     def refill(self):
         """Fresh random actions into the SAME W + K device buffers (so a captured graph stays valid); untimed."""
-        torch, env = self.torch, self.env
+        env = self.env
         self.passes += 1
         if self.flying:
-            mv, cam, inv, plc = self.acts
-            mv.uniform_(-1, 1, generator=self.g)        # movement ~ U(-1, 1)^3
-            cam.uniform_(-5, 5, generator=self.g)       # camera ~ U(-5, 5)^2
-            inv.random_(0, 7, generator=self.g)
-            plc.random_(0, 3, generator=self.g)
+            self.acts['movement'].uniform_(-1, 1, generator=self.g)     # movement ~ U(-1, 1)^3
+            self.acts['camera'].uniform_(-5, 5, generator=self.g)       # camera ~ U(-5, 5)^2
+            self.acts['inventory'].random_(0, 7, generator=self.g)
+            self.acts['placement'].random_(0, 3, generator=self.g)
         else:
             t0 = self.passes * (self.W + self.K)
-            for a in self.actions:
-                self.L.check(env.lib.igw_fill_actions_walking(env.ctx, a.data_ptr(), a.shape[0], t0, self.args.seed,
-                                                              self.env_offset, env._stream()), 'igw_fill_actions_walking')
-                t0 += a.shape[0]
-
-    def step(self, t, stream):
-        p = self.ptrs[t]
-        rc = self._fn(self._ctx, *p, stream) if self.flying else self._fn(self._ctx, p, stream)
-        if rc:
-            self.L.check(rc, 'igw_step')
+            self.L.check(env.lib.igw_fill_actions_walking(env.ctx, self.acts.data_ptr(), self.acts.shape[0], t0, self.args.seed,
+                                                          self.env_offset, env._stream()), 'igw_fill_actions_walking')
 
     def busy(self, seconds, min_steps, fresh=True):
         """Untimed stepping with FRESH random actions: the pre-roll to the steady state / the clock ramp."""
@@ -359,7 +372,7 @@ class Runner:
                 if fresh:
                     self.refill()
                 for t in range(min(self.W + self.K, 128)):
-                    self.step(t, env._stream())
+                    env.step(self.act_t[t])
                 n_pre += min(self.W + self.K, 128)
             else:  # fused rollout with in-kernel random actions
                 env.rollout(MAX_STEPS, seed=self.args.seed + 17 + self.pre_rolled, t0=self.pre_rolled, env_offset=self.env_offset)
@@ -367,45 +380,38 @@ class Runner:
                 self.pre_rolled += MAX_STEPS
             torch.cuda.synchronize(self.device)
 
-    # -- the timed launches as a short eager head + ONE HIP graph for the rest --------------------------------
+    # -- the timed steps: a short eager head of env.step() calls + ONE replay of a captured step graph ------------
     def _capture(self):
-        """Capture records launches without running them (the entry points never synchronise or allocate) and
-        instantiation happens here, before the warm-up and the clock.  The eager head starts the GPU within a few
-        microseconds of the clock; the graph is launched while those kernels run, so its launch latency (10-16 us)
-        is off the critical path.  With other ranks alive (an RCCL watchdog thread may touch the runtime) the capture
-        is thread-local; if capture or instantiation fails the window is timed as eager launches, in this process."""
+        """VecGridWorld.capture_steps records the launches of steps W + head .. W + K - 1 without running them (the entry
+        points never synchronise or allocate); instantiation happens here, before the warm-up and the clock.  The eager
+        head starts the GPU within a few microseconds of the clock; the graph is launched while those kernels run, so
+        its launch latency (10-16 us) is off the critical path.  If capture or instantiation fails the window is timed as
+        eager env.step() calls, in this process."""
         torch, W, K = self.torch, self.W, self.K
         # eager launches while the host is still busy launching the graph (the first launch after a synchronize takes
-        # ~15 us of host time, an event record ~7, a graph launch ~20; a kernel ~14): with a head of 2 the GPU ran out
+        # ~15 us of host time, an event record ~7, a graph launch ~20; a kernel ~12): with a head of 2 the GPU ran out
         # of work for ~15 us before the graph arrived
         head = min(int(os.environ.get('IGW_BENCH_HEAD', 6)), K - 2)   # (IGW_BENCH_HEAD: experiments only)
         try:
-            graph = torch.cuda.CUDAGraph()
-            cap = torch.cuda.Stream(device=self.device)
-            cap.wait_stream(torch.cuda.current_stream(self.device))
-            mode = 'thread_local' if self.world > 1 else 'global'
-            with torch.cuda.graph(graph, stream=cap, capture_error_mode=mode):
-                cap_h = ctypes.c_void_p(cap.cuda_stream)
-                for t in range(W + head, W + K):
-                    self.step(t, cap_h)
-            torch.cuda.current_stream(self.device).wait_stream(cap)
+            sub = {k: v[W + head:] for k, v in self.acts.items()} if self.flying else self.acts[W + head:]
+            graph = self.env.capture_steps(sub)
             graph.replay()  # part of the setup: the first launch of a graph also uploads it
             torch.cuda.synchronize(self.device)
             self.graph, self.head = graph, head
-            self.timed_as = f'{head} eager launches + one HIP-graph replay of the other {K - head}'
+            self.timed_as = f'{head} eager env.step() calls + one replay of VecGridWorld.capture_steps over the other {K - head}'
         except Exception as e:  # noqa: BLE001 -- any capture / instantiate failure: eager launches instead
             try:
                 torch.cuda.synchronize(self.device)
             except Exception:  # noqa: BLE001
                 pass
             self.graph, self.head = None, K
-            self.timed_as = 'eager launches (graph capture failed: %s)' % (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
+            self.timed_as = 'eager env.step() calls (graph capture failed: %s)' % (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
 
     def window(self):
         """Refill (untimed), W untimed warm-up steps, then the clock around exactly K steps.  Returns (wall seconds,
         counters before the clock as a device tensor, kernel ms per launch from HIP events, host timeline)."""
-        torch, env, W, K, cur_h = self.torch, self.env, self.W, self.K, self.cur_h
-        ev0, ev1 = self.ev0, self.ev1
+        torch, env, W, K = self.torch, self.env, self.W, self.K
+        ev0, ev1, act_t, step = self.ev0, self.ev1, self.act_t, self.env.step
         # Between two windows the host reads counters and refills buffers: the GPU idles for hundreds of microseconds
         # and its clocks drop; W = 5 warm-up steps (65 us) do not bring them back, and the first kernels of the window
         # would run 2-3 % slower than in a long run.  So: about 2 ms of untimed stepping with fresh random actions
@@ -416,7 +422,7 @@ class Runner:
         # warm-up right before the clock; the counters are snapshotted on the device, not read, so nothing idles
         # the GPU between warm-up and clock
         for t in range(W):
-            self.step(t, cur_h)
+            step(act_t[t])
         before = env.stats_buf.sum(0)
         ev0.record()   # torch creates the HIP events lazily at their first record(): not inside the clock
         ev1.record()
@@ -426,7 +432,7 @@ class Runner:
         if K == 1:
             ev0.record()
         t_start = time.perf_counter()
-        self.step(W, cur_h)
+        step(act_t[W])
         # The HIP-event window (kernel duration for the roofline) opens behind the first timed launch and spans the
         # other K - 1: an event recorded on the idle stream would be processed at once and the window would then
         # contain the launch latency of the first kernel, not only kernels.  The GPU is busy with that first launch
@@ -434,15 +440,14 @@ class Runner:
         if K > 1:
             ev0.record()
         for t in range(W + 1, W + self.head):
-            self.step(t, cur_h)
+            step(act_t[t])
         t_b = time.perf_counter()
         if self.graph is not None:
             self.graph.replay()
         t_c = time.perf_counter()
         ev1.record()
         t_d = time.perf_counter()
-        while not ev1.query():  # spin: a blocking synchronize sleeps on an interrupt and wakes tens of us late
-            pass
+        spin_until(ev1.query)  # spin (with back-off): a blocking synchronize sleeps on an interrupt and wakes tens of us late
         t_e = time.perf_counter()
         torch.cuda.synchronize(self.device)
         t_f = time.perf_counter()
@@ -450,6 +455,52 @@ class Runner:
         t_end = time.perf_counter()
         kernel_ms = ev0.elapsed_time(ev1) / max(K - 1, 1)  # the event window spans the last K - 1 timed launches
         return t_end - t_start, before, kernel_ms, (t_b - t_start, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e, t_end - t_f)
+
+    def api_loops(self, reps=5):
+        """What a user of the public API gets, measured the way examples/run_env.py:18-26 loops: a plain
+        `for t in range(K): obs, reward, done, info = env.step(actions[t])` (the slice included) between two
+        synchronizes -- eager, for K = 20 and K = the run's K -- and the same K steps as ONE replay of
+        env.capture_steps(actions[:K]).  Median of `reps` passes each (actions refilled before every pass; 2 ms of
+        untimed stepping first, as before every window)."""
+        torch, env, N = self.torch, self.env, self.N
+        acts = self.acts
+        out = {'eager': {}, 'graph': {}}
+
+        def one(K, fn):
+            ts = []
+            for _ in range(reps):
+                if not self.args.lockstep:
+                    self.busy(0.002, 0, fresh=False)
+                self.refill()
+                for t in range(self.W):
+                    env.step(self.act_t[t])
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                fn(K)
+                torch.cuda.synchronize(self.device)
+                ts.append(time.perf_counter() - t0)
+            return N * K / statistics.median(ts)
+
+        def eager(K):
+            if self.flying:
+                for t in range(K):
+                    env.step({'movement': acts['movement'][t], 'camera': acts['camera'][t],
+                              'inventory': acts['inventory'][t], 'placement': acts['placement'][t]})
+            else:
+                for t in range(K):
+                    env.step(acts[t])
+        for K in sorted({min(20, self.K), self.K}):
+            out['eager'][str(K)] = one(K, eager)
+            try:
+                g = env.capture_steps({k: v[:K] for k, v in acts.items()} if self.flying else acts[:K])
+                g.replay()
+                torch.cuda.synchronize(self.device)
+                out['graph'][str(K)] = one(K, lambda K: g.replay())
+                del g
+            except Exception as e:  # noqa: BLE001
+                out['graph'][str(K)] = None
+                out['graph_error'] = str(e).splitlines()[0][:160] if str(e) else type(e).__name__
+        return out
 
     def measure(self, windows, rehearsals):
         """`rehearsals` passes that are reported but not counted, then `windows` measured ones.  The first passes
@@ -536,6 +587,7 @@ def roofline_of(r, m, lanes, has_start_frac=0.0):
         waves_per_simd = (N * lanes / 64.0) / 1024.0   # 256 CUs x 4 SIMDs
         iss = {'bound': 'issue', 'source': issue.get('_file'),
                'from_profile': {k: issue.get(k) for k in ('valu_insts_per_wave', 'salu_insts_per_wave', 'lds_insts_per_wave',
+                                                          'vmem_rd_insts_per_wave', 'vmem_wr_insts_per_wave',
                                                           'frac_wave_time_parked_on_waitcnt', 'frac_wave_time_issue_stalled',
                                                           'frac_wave_time_issuing', 'kernel_avg_ns', 'dispatches_averaged')},
                'waves_per_simd': waves_per_simd,
@@ -543,6 +595,15 @@ def roofline_of(r, m, lanes, has_start_frac=0.0):
                # issuing VALU instructions (instruction count of the profile, kernel time of this run)
                'valu_issue_util_per_simd': None if not valu else valu * waves_per_simd * 4.0 / (kernel_ms * 1e-3 * GPU_CLOCK_GHZ * 1e9),
                'valu_insts_per_env_step': None if not valu else valu * lanes / 64.0}
+    # the bound that binds, inside `roofline` itself: the issue side and the measured HBM side next to the convention
+    roof['issue_util'] = None if iss is None else iss['valu_issue_util_per_simd']
+    roof['hbm_frac_measured'] = roof['hbm_measured_frac']
+    roof['note'] = ('`frac` follows the SURVEY 8(d) convention (the 1,089-byte int8 grid priced every step); this design keeps a '
+                    '192-byte occupancy bitmap of it and streams ~0.5 KB per env-step, so `frac` rises with any speed-up and '
+                    'exceeds 1 at 524,288 envs per launch (1.10-1.15) although no work is skipped -- the bytes are not moved. '
+                    'The kernel is bound by per-wavefront dependent-issue latency: `issue_util` = VALU-issue utilisation of a '
+                    'SIMD (instruction count of the committed SQ profile x this run\'s kernel time), `hbm_frac_measured` = PMC '
+                    'bytes of the committed profile / this run\'s kernel time / peak.')
     return roof, iss
 
 
@@ -552,6 +613,14 @@ def main():
         raise SystemExit(self_launch(args))
     if args.dry_run:
         return dry_run(args)
+    from gridworld_amd import dist as gdist
+    try:
+        run(args)
+    finally:
+        gdist.shutdown()   # closing barrier + destroy_process_group: no rank falls off the end while others still talk
+
+
+def run(args):
 
     import torch
     from gridworld_amd import _lib as L, dist as gdist
@@ -569,6 +638,7 @@ def main():
     # costs 50-100 us, a quarter of a 20-step window)
     node_barrier = gdist.NodeBarrier()
 
+    torch.set_num_threads(max(1, usable_cpus() // world))   # host-side torch work of a rank stays within its share of the quota
     r = Runner(args, args.mode, args.workload, device, rank, world, node_barrier)
     env = r.env
     m = r.measure(args.windows, args.rehearsals)
@@ -576,6 +646,8 @@ def main():
     max_elapsed = m['elapsed']
     ranks_seen, gather_via = gdist.gather_counts_rccl(rank, device)   # the one RCCL collective: per-rank step counts
     n_ranks = len(ranks_seen)
+    kernel_us_per_rank = [round(x, 3) for x in gdist.gather_floats(1e3 * m['kernel_ms'])]   # (control plane)
+    api = r.api_loops() if not args.no_api else None
 
     # secondary: fused T-step rollout (state resident in LDS/registers, in-kernel RNG)
     fused = fused_rec = None
@@ -590,21 +662,22 @@ def main():
         gdist.barrier()
         f_steps, f_el = gdist.reduce_window(N * Tf, time.perf_counter() - t0)
         fused = f_steps / f_el
-        # the same fused loop over RECORDED actions (igw_rollout_walking_actions): the first chunk of the timed actions
-        Tr = r.actions[0].shape[0]
-        env.rollout_actions(r.actions[0])  # warm
+        # the same fused loop over RECORDED actions (igw_rollout_walking_actions): the first 256 of the timed actions
+        rec_acts = r.acts[:min(256, r.acts.shape[0])]
+        Tr = rec_acts.shape[0]
+        env.rollout_actions(rec_acts)  # warm
         torch.cuda.synchronize(device)
         gdist.barrier()
         t0 = time.perf_counter()
-        env.rollout_actions(r.actions[0])
+        env.rollout_actions(rec_acts)
         torch.cuda.synchronize(device)
         gdist.barrier()
         r_steps, r_el = gdist.reduce_window(N * Tr, time.perf_counter() - t0)
         fused_rec = r_steps / r_el
 
     if flying and not args.no_fused:   # the fused loop over the recorded flying actions (igw_rollout_flying_actions)
-        rec = dict(movement=r.acts[0], camera=r.acts[1], inventory=r.acts[2], placement=r.acts[3])
-        Tr = r.acts[0].shape[0]
+        rec = r.acts
+        Tr = r.acts['movement'].shape[0]
         env.rollout_actions(rec)  # warm
         torch.cuda.synchronize(device)
         gdist.barrier()
@@ -623,6 +696,7 @@ def main():
         subs = env.split(2)
         jobs = [(sb.ctx, ctypes.c_void_p(sb.stream.cuda_stream), 4 * sb.lo) for sb in subs]
         Ka = min(K, W + K)
+        act_ptrs = [a.data_ptr() for a in r.act_t]
         walk_fn = env.lib.igw_step_walking
         torch.cuda.synchronize(device)
         for timed in (False, True):
@@ -631,7 +705,7 @@ def main():
             t0 = time.perf_counter()
             for t in range(Ka):
                 for ctx_s, st_s, off in jobs:
-                    rc = walk_fn(ctx_s, r.ptrs[t] + off, st_s)
+                    rc = walk_fn(ctx_s, act_ptrs[t] + off, st_s)
                     if rc:
                         L.check(rc, 'igw_step_walking')
             torch.cuda.synchronize(device)
@@ -674,7 +748,7 @@ def main():
             torch.cuda.empty_cache()
 
     if rank != 0:
-        return
+        return None
     wl_text = {('walking', 'rt20'): 'configs[2]: 65,536 parallel envs per GPU, walking Discrete(18), random 20-block '
                                     'targets (rt20), full maximal_intersection reward, uniform random actions, '
                                     'auto-reset at done (max_steps=250)',
@@ -717,18 +791,31 @@ def main():
                    'rehearsal_ms_per_step': m['rehearsal_ms_per_step'],
                    'resets_in_window': m['resets_in_window'], 'p_changed': m['p_changed'],
                    'p_cell_changed': m['p_cell_changed'],
-                   'step_count_gather': gather_via,
+                   'step_count_gather': gather_via, 'ranks_seen': ranks_seen, 'kernel_us_per_rank': kernel_us_per_rank,
+                   'host': {'usable_cpus': usable_cpus(), 'torch_threads': torch.get_num_threads()},
                    'fused_rollout_env_steps_per_s': fused,
                    'fused_rollout_recorded_actions_env_steps_per_s': fused_rec,
                    'async_2_subbatches_env_steps_per_s': async2},
         'roofline': roof,
     }
+    if api is not None:
+        head = out['value'] / n_ranks   # this rank's share: the API loops are per rank, not reduced
+        out['config']['api_step_env_steps_per_s'] = api['eager']
+        out['config']['api_graph_env_steps_per_s'] = api['graph']
+        out['config']['api_note'] = ('rank 0, walking: `for t in range(K): env.step(actions[t])` through VecGridWorld.step '
+                                     '(eager, slice included) / ONE replay of VecGridWorld.capture_steps(actions[:K]); '
+                                     'keys = K; between two synchronizes, median of 5 passes; `value` itself is timed through '
+                                     'the same public calls (config.timed_as)')
+        out['config']['api_vs_value'] = {'eager': {k: (v / head if v else None) for k, v in api['eager'].items()},
+                                         'graph': {k: (v / head if v else None) for k, v in api['graph'].items()}}
+        if 'graph_error' in api:
+            out['config']['api_graph_error'] = api['graph_error']
     out['config'].update(secondary)
     if iss is not None:
         out['issue'] = iss
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.seed)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -13,13 +13,15 @@ LIB_PATH = os.path.join(HERE, 'libigw_hip.so')
 GRID_STRIDE = 1104
 CELLS = 1089
 AGENT_BYTES = 64
+AUX_BYTES = 16
+OUT_BYTES = 64
 TASK_META_BYTES = 128
 OCC_WORDS = 48
 TRAJ_BYTES = 64
 HIST_ROW = 512
 STAT_STRIPES = 64
 STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS, STAT_BAD_POSE, STAT_BAD_ACTION, STAT_BAD_TASK = 0, 1, 2, 3, 4, 5, 6
-VERSION = 3
+VERSION = 4
 LEVEL_INDEX_BYTES = 160
 TASK_INDEX_BYTES = 9 * LEVEL_INDEX_BYTES
 WALKING_DISCRETE, FLYING, WALKING_DICT = 0, 1, 2
@@ -46,9 +48,8 @@ class Config(C.Structure):
 
 
 class Buffers(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('grid', 'occ', 'hist', 'agent', 'env_task', 'task_target', 'task_start',
-                                          'task_start_occ', 'task_meta', 'agent_pos', 'inventory', 'compass',
-                                          'reward', 'done', 'stats', 'episode', 'task_index')]
+    _fields_ = [(n, C.c_void_p) for n in ('grid', 'occ', 'hist', 'agent', 'aux', 'task_target', 'task_start',
+                                          'task_start_occ', 'task_meta', 'task_index', 'out', 'stats')]
 
 
 _lib = None
@@ -97,6 +98,7 @@ def load(build_if_missing=True):
     L.igw_rollout_flying_actions.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp]
     L.igw_fill_actions_walking.argtypes = [vp, vp, i64, i64, u64, i64, vp]
     L.igw_task_eval.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.igw_debug_trig.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)
         if name not in ('igw_last_error',):

@@ -85,15 +85,32 @@ constexpr double PAD = 0.25;
 constexpr double PI_OVER_180 = 0x1.1df46a2529d39p-6;   // pi / 180  (CPython math.radians)
 constexpr double D180_OVER_PI = 0x1.ca5dc1a63c1f8p+5;  // 180 / pi  (CPython math.degrees)
 
-struct alignas(16) AgentRec {  // layout documented in include/igw.h
+struct alignas(16) AgentRec {  // layout documented in include/igw.h; rewritten whole by every step
     double x, y, z, yaw, pitch, vy;
+    int16_t inv[6];    // agent.inventory (20 - blocks of the colour in the world: -1069..20)
     uint16_t step_no;
-    int16_t size, prev_size, max_int;
-    // bytes 0..5 inventory (int8); bits 48-49 time_int_steps code (2,4,8,12), bits 50-52 active_block,
-    // bits 53-63 target_size of the synthetic task (copied from the task table by reset)
-    uint64_t inv_pack;
+    uint16_t pack;     // bits 0-1 time_int_steps code (2,4,8,12), bits 2-4 active_block
 };
 static_assert(sizeof(AgentRec) == IGW_AGENT_BYTES, "agent record layout");
+
+struct alignas(16) AuxRec {  // episode state: read by every step, written only when it changes
+    int16_t size;
+    uint16_t prev_size;  // bit 15: dirty
+    int16_t max_int, target_size;
+    int32_t task;
+    uint32_t episode;
+};
+static_assert(sizeof(AuxRec) == IGW_AUX_BYTES, "aux record layout");
+
+struct alignas(16) OutRec {  // per-step outputs (env.py:281-303), written whole by every step
+    float agent_pos[5];
+    float inventory[6];
+    float compass;
+    float reward;
+    uint8_t done;
+    uint8_t pad[11];
+};
+static_assert(sizeof(OutRec) == IGW_OUT_BYTES && offsetof(OutRec, reward) == 48, "output record layout");
 
 struct alignas(16) TaskMeta {
     double pose[5];
@@ -101,10 +118,11 @@ struct alignas(16) TaskMeta {
     uint8_t has_start;
     uint8_t pad0[3];
     int8_t bbox[16];  // offset 48: one aligned dwordx4
-    int8_t inv_init[6];
-    uint8_t pad[IGW_TASK_META_BYTES - 70];
+    int16_t inv_init[6];
+    uint8_t pad[IGW_TASK_META_BYTES - 76];
 };
 static_assert(offsetof(TaskMeta, bbox) == 48, "bbox must be 16-byte aligned");
+static_assert(offsetof(TaskMeta, inv_init) == 64, "inv_init is one aligned dwordx4 (with 4 bytes of padding)");
 static_assert(sizeof(TaskMeta) == IGW_TASK_META_BYTES, "task meta layout");
 
 struct KParams {
@@ -120,19 +138,14 @@ struct KParams {
     uint32_t* occ;
     uint16_t* hist;
     AgentRec* agent;
-    int32_t* env_task;
+    AuxRec* aux;
     const int8_t* task_target;
     const int8_t* task_start;
     const uint32_t* task_start_occ;
     const TaskMeta* task_meta;
     const uint8_t* task_index;   // [T][IGW_TASK_INDEX_BYTES] colour index of the synthetic targets (include/igw.h)
-    float* agent_pos;
-    float* inventory;
-    float* compass;
-    float* reward;
-    uint8_t* done;
+    OutRec* out;
     unsigned long long* stats;
-    uint32_t* episode;           // [N] episodes started per env (keys the samplers and the trajectory log)
     uint8_t* traj;               // [traj_n][2][traj_cap][IGW_TRAJ_BYTES]
     int32_t* traj_heads;         // [traj_n][2][4]
     unsigned long long* stamps;  // diagnostic builds only: [waves][8] s_memtime stamps (igw_debug_set_stamps)
@@ -270,56 +283,115 @@ __host__ __device__ inline int rng_action18(uint64_t seed, uint64_t env, uint64_
 struct Env {  // uniform across the lanes of a group
     double x, y, z, yaw, pitch, vy;
     int step_no, size, prev_size, max_int;
-    uint64_t inv;  // 6 x int8
+    uint32_t inv01, inv23, inv45;  // agent.inventory: 6 x int16, two per word (the record's layout)
     int tis, active, target_size;
     int dirty;  // the histogram changed since max_int was last refreshed (a change with wrong_placement == 0)
+    uint32_t episode;  // episodes started (aux record)
 };
 
-__device__ inline int inv_get(uint64_t inv, int i) { return (int)(int8_t)(inv >> (8 * i)); }
-__device__ inline uint64_t inv_add(uint64_t inv, int i, int d) {
-    int v = inv_get(inv, i) + d;
-    int sh = 8 * i;
-    return (inv & ~(0xffull << sh)) | ((uint64_t)(uint8_t)v << sh);
+// inventory[i], i in 0..5 (i is data, not a constant: selects between the three words, BY VALUE -- a select between
+// fields of the env struct becomes a load from a selected address and parks the struct in scratch memory)
+__device__ __forceinline__ int inv_pick(uint32_t i01, uint32_t i23, uint32_t i45, int i) {
+    const uint32_t pair = i < 2 ? i01 : i < 4 ? i23 : i45;
+    return (int)(int16_t)(pair >> ((i & 1) << 4));
 }
+__device__ __forceinline__ uint32_t inv_put(uint32_t pair, int i, int v) {
+    return (i & 1) ? (pair & 0x0000ffffu) | ((uint32_t)v << 16) : (pair & 0xffff0000u) | ((uint32_t)v & 0xffffu);
+}
+__device__ inline int inv_get(const Env& e, int i) {
+    const uint32_t a = e.inv01, b = e.inv23, c = e.inv45;
+    return inv_pick(a, b, c, i);
+}
+__device__ inline void inv_add(Env& e, int i, int d) {
+    const uint32_t a = e.inv01, b = e.inv23, c = e.inv45;
+    const int v = inv_pick(a, b, c, i) + d;
+    e.inv01 = i < 2 ? inv_put(a, i, v) : a;
+    e.inv23 = (i >= 2 && i < 4) ? inv_put(b, i, v) : b;
+    e.inv45 = i >= 4 ? inv_put(c, i, v) : c;
+}
+__device__ inline int inv_lo(uint32_t pair) { return (int)(int16_t)(pair & 0xffffu); }
+__device__ inline int inv_hi(uint32_t pair) { return (int)pair >> 16; }
+constexpr uint32_t INV_FULL_PAIR = 20u | (20u << 16);  // Agent.__init__ / reset without a starting grid: 20 of each colour
 
-__device__ inline void env_unpack(Env& e, const AgentRec& r) {
-    e.x = r.x; e.y = r.y; e.z = r.z; e.yaw = r.yaw; e.pitch = r.pitch; e.vy = r.vy;
-    e.step_no = r.step_no; e.size = r.size; e.prev_size = r.prev_size & 0x7fff; e.max_int = r.max_int;
-    e.dirty = ((uint16_t)r.prev_size >> 15) & 1;
-    e.inv = r.inv_pack & 0x0000ffffffffffffull;
-    const int code = (int)((r.inv_pack >> 48) & 3);
+// The raw words of the two records as the kernels move them: the agent record's fourth 16-byte piece and the aux record.
+__device__ inline void env_unpack_piece3(Env& e, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    e.inv01 = w0; e.inv23 = w1; e.inv45 = w2;
+    e.step_no = (int)(w3 & 0xffffu);
+    const int code = (int)((w3 >> 16) & 3u);
     e.tis = code == 0 ? 2 : code == 1 ? 4 : code == 2 ? 8 : 12;
-    e.active = (int)((r.inv_pack >> 50) & 7);
-    e.target_size = (int)(r.inv_pack >> 53);
+    e.active = (int)((w3 >> 18) & 7u);
 }
-__device__ inline void env_load(Env& e, const AgentRec* rec) {
-    // every lane reads the same 64 B line (one request per wave)
-    const AgentRec r = *rec;
-    env_unpack(e, r);
+__device__ inline uint4 env_pack_piece3(const Env& e) {
+    const uint32_t code = e.tis == 2 ? 0u : e.tis == 4 ? 1u : e.tis == 8 ? 2u : 3u;
+    return make_uint4(e.inv01, e.inv23, e.inv45, (uint32_t)(e.step_no & 0xffff) | (code << 16) | ((uint32_t)(e.active & 7) << 18));
 }
-// The record is stored in two parts: the pose (bytes 0..47) is final as soon as the physics has run, the
-// counters (bytes 48..63) only after the reward tail.
+// aux record: {size | prev_size (+ dirty) << 16, max_int | target_size << 16, task, episode}
+__device__ inline void env_unpack_aux(Env& e, uint32_t a0, uint32_t a1, uint32_t a3) {
+    e.size = (int)(int16_t)(a0 & 0xffffu);
+    e.prev_size = (int)((a0 >> 16) & 0x7fffu);
+    e.dirty = (int)(a0 >> 31);
+    e.max_int = (int)(int16_t)(a1 & 0xffffu);
+    e.target_size = (int)a1 >> 16;
+    e.episode = a3;
+}
+__device__ inline uint4 env_pack_aux(const Env& e, int task) {
+    return make_uint4(((uint32_t)e.size & 0xffffu) | ((uint32_t)((e.prev_size & 0x7fff) | (e.dirty << 15)) << 16),
+                      ((uint32_t)e.max_int & 0xffffu) | ((uint32_t)e.target_size << 16), (uint32_t)task, e.episode);
+}
+__device__ inline void env_unpack(Env& e, const AgentRec& r, const uint4& aux) {
+    e.x = r.x; e.y = r.y; e.z = r.z; e.yaw = r.yaw; e.pitch = r.pitch; e.vy = r.vy;
+    uint32_t w[4];
+    __builtin_memcpy(w, &r.inv[0], 16);
+    env_unpack_piece3(e, w[0], w[1], w[2], w[3]);
+    env_unpack_aux(e, aux.x, aux.y, aux.w);
+}
+// whole-record load (kernels without the spread burst of step_kernel); returns the env's task
+__device__ inline int env_load(Env& e, const AgentRec* rec, const AuxRec* aux) {
+    const AgentRec r = *rec;  // every lane reads the same 64 B line (one request per wave)
+    const uint4 a = *reinterpret_cast<const uint4*>(aux);
+    env_unpack(e, r, a);
+    return (int)a.z;
+}
 typedef double vd2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long vu2 __attribute__((ext_vector_type(2)));
+typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
 // Per-step outputs are written once and next read by another launch: non-temporal stores (-1 % launch time).
 template <class T> __device__ inline void st(T* p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void st4(void* p, const uint4& v) { st(reinterpret_cast<vu4*>(p), vu4{v.x, v.y, v.z, v.w}); }
 __device__ inline void env_store_pose(const Env& e, AgentRec* rec) {
     vd2* d = reinterpret_cast<vd2*>(rec);
     st(d + 0, vd2{e.x, e.y});
     st(d + 1, vd2{e.z, e.yaw});
     st(d + 2, vd2{e.pitch, e.vy});
 }
-__device__ inline void env_store_counters(const Env& e, AgentRec* rec) {
-    const uint64_t lo = (uint64_t)(uint16_t)e.step_no | ((uint64_t)(uint16_t)(int16_t)e.size << 16) |
-                        ((uint64_t)(uint16_t)((e.prev_size & 0x7fff) | (e.dirty << 15)) << 32) |
-                        ((uint64_t)(uint16_t)(int16_t)e.max_int << 48);
-    const uint64_t code = e.tis == 2 ? 0 : e.tis == 4 ? 1 : e.tis == 8 ? 2 : 3;
-    const uint64_t hi = e.inv | (code << 48) | ((uint64_t)(e.active & 7) << 50) | ((uint64_t)(e.target_size & 0x7ff) << 53);
-    st(reinterpret_cast<vu2*>(rec) + 3, vu2{lo, hi});
-}
+// one lane stores the whole agent record (and, separately, the aux record)
 __device__ inline void env_store(const Env& e, AgentRec* rec) {
     env_store_pose(e, rec);
-    env_store_counters(e, rec);
+    st4(reinterpret_cast<uint4*>(rec) + 3, env_pack_piece3(e));
+}
+__device__ inline void aux_store(const Env& e, int task, AuxRec* aux) { st4(aux, env_pack_aux(e, task)); }
+
+// The output record (include/igw.h) as its four 16-byte pieces: agentPos[0..3] | agentPos[4], inventory[0..2] |
+// inventory[3..5], compass | reward, done.
+__device__ inline uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ inline uint4 out_piece(const Env& e, int q, float a0, float a1, float a2, float a3, float a4, float compass) {
+    const float i0 = (float)inv_lo(e.inv01), i1 = (float)inv_hi(e.inv01), i2 = (float)inv_lo(e.inv23),
+                i3 = (float)inv_hi(e.inv23), i4 = (float)inv_lo(e.inv45), i5 = (float)inv_hi(e.inv45);
+    return make_uint4(f2u(q == 0 ? a0 : q == 1 ? a4 : i3), f2u(q == 0 ? a1 : q == 1 ? i0 : i4),
+                      f2u(q == 0 ? a2 : q == 1 ? i1 : i5), f2u(q == 0 ? a3 : q == 1 ? i2 : compass));
+}
+__device__ inline uint4 out_piece_step(const Env& e, int q) {  // obs of step(): env.py:281-289
+    return out_piece(e, q, (float)e.x, (float)e.y, (float)e.z, (float)e.pitch, (float)e.yaw, (float)(e.yaw - 180.0));
+}
+__device__ inline uint4 out_piece_reset(const Env& e, int q) {  // obs of reset(): agentPos zeros, compass 0 (env.py:247-254)
+    return out_piece(e, q, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+}
+__device__ inline uint4 out_piece_result(float reward, bool done) { return make_uint4(f2u(reward), done ? 1u : 0u, 0u, 0u); }
+// one lane writes the whole record
+__device__ inline void out_store(OutRec* o, const Env& e, bool reset_obs, float reward, bool done) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) st4(reinterpret_cast<uint4*>(o) + q, reset_obs ? out_piece_reset(e, q) : out_piece_step(e, q));
+    st4(reinterpret_cast<uint4*>(o) + 3, out_piece_result(reward, done));
 }
 
 // ---------------------------------------------------------------- world queries

@@ -109,38 +109,14 @@ __device__ inline void rot_bboxes(const BBox& b, bool empty, int* out4) {
     out4[3] = pack_bbox(10 - b.zmax, 10 - b.zmin, b.xmin, b.xmax);
 }
 
-// per-lane part of GridWorld.reset (env.py:206-261): everything except the grid / bitmap rows.
-// generated_size >= 0: the task row was just written by the on-device RandomTasks generator of this wave (its
-// metadata is taken from registers, not re-read: target size as given, empty start => full inventory).
-__device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_size, int generated_size = -1) {
-    if (!keep_size) e.size = 0;  // SizeReward.reset, env.py:321-323
-    e.step_no = 0;               // env.py:217
-    e.prev_size = 0;             // _synthetic_task.reset(): prev_grid_size = 0, max_int = 0 (task.py:74-86)
-    e.max_int = 0;
-    e.dirty = 0;
-    e.x = meta->pose[0]; e.y = meta->pose[1]; e.z = meta->pose[2];  // env.py:239-240
-    e.yaw = meta->pose[3]; e.pitch = meta->pose[4];
-    if (generated_size >= 0) {
-        e.target_size = generated_size;
-        e.inv = 0x141414141414ull;  // 20 of each colour
-    } else {
-        e.target_size = meta->target_size;
-        uint64_t inv = 0;  // env.py:243-246
-#pragma unroll
-        for (int i = 0; i < 6; i++) inv |= (uint64_t)(uint8_t)meta->inv_init[i] << (8 * i);
-        e.inv = inv;
-    }
-    // agent.dy, time_int_steps, active_block are NOT reset by the reference
-}
-
-// What GridWorld.reset takes from the task's metadata row, as registers: a wavefront that knows at the START of a
+// What GridWorld.reset takes from the task's metadata row, as registers.  A wavefront that knows at the START of a
 // step that one of its episodes runs out in it (step_no + 1 == max_steps, the usual end of an episode) fetches
 // these with the step's other inputs instead of at the end, where two dependent memory round trips -- each behind an
 // s_waitcnt that also waits for the step's stores -- used to make the resetting wavefront the last of its CU.
 struct ResetMeta {
     double pose[5];
     int target_size;
-    uint64_t inv;
+    uint32_t inv01, inv23, inv45;  // env.py:243-246: 20 - blocks of the colour in the starting grid
     bool has_start;
 };
 __device__ inline ResetMeta load_reset_meta(const TaskMeta* meta) {
@@ -149,12 +125,13 @@ __device__ inline ResetMeta load_reset_meta(const TaskMeta* meta) {
     for (int i = 0; i < 5; i++) r.pose[i] = meta->pose[i];
     r.target_size = meta->target_size;
     r.has_start = meta->has_start != 0;
-    uint64_t inv = 0;  // env.py:243-246
-#pragma unroll
-    for (int i = 0; i < 6; i++) inv |= (uint64_t)(uint8_t)meta->inv_init[i] << (8 * i);
-    r.inv = inv;
+    const uint4 iv = *reinterpret_cast<const uint4*>(meta->inv_init);  // (one aligned dwordx4; the fourth word is padding)
+    r.inv01 = iv.x; r.inv23 = iv.y; r.inv45 = iv.z;
     return r;
 }
+// per-lane part of GridWorld.reset (env.py:206-261): everything except the grid / bitmap rows.
+// generated_size >= 0: the task row was just written by the on-device RandomTasks generator of this wave (its
+// metadata is taken from registers, not re-read: target size as given, empty start => full inventory).
 __device__ inline void reset_env_regs(Env& e, const ResetMeta& m, bool keep_size, int generated_size = -1) {
     if (!keep_size) e.size = 0;  // SizeReward.reset, env.py:321-323
     e.step_no = 0;               // env.py:217
@@ -165,32 +142,27 @@ __device__ inline void reset_env_regs(Env& e, const ResetMeta& m, bool keep_size
     e.yaw = m.pose[3]; e.pitch = m.pose[4];
     if (generated_size >= 0) {   // the row was just written by the on-device generator: empty start, full inventory
         e.target_size = generated_size;
-        e.inv = 0x141414141414ull;
+        e.inv01 = e.inv23 = e.inv45 = INV_FULL_PAIR;
     } else {
         e.target_size = m.target_size;
-        e.inv = m.inv;
+        e.inv01 = m.inv01; e.inv23 = m.inv23; e.inv45 = m.inv45;
     }
     // agent.dy, time_int_steps, active_block are NOT reset by the reference
 }
+__device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_size, int generated_size = -1) {
+    reset_env_regs(e, load_reset_meta(meta), keep_size, generated_size);
+}
 
 // A reset counts a new episode and, with a task generator on the device, picks the env's next task row.
-// Returns the number of the episode that ends (the samplers' key).  `leader`: the one lane that stores.
-__device__ inline uint32_t next_task(const KParams& p, int env, bool leader, int& task) {
-    uint32_t ep = 0;
-    if (p.episode) {
-        if (p.sample_tasks || p.rt_enabled || p.traj) {  // somebody needs the number: read, then count
-            ep = __hip_atomic_load(p.episode + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (leader) p.episode[env] = ep + 1;
-        } else if (leader) {  // just count: an atomic without return, nothing on the reset path waits for memory
-            __hip_atomic_fetch_add(p.episode + env, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+// Returns the number of the episode that ends (the samplers' key).  Task and counter live in the env's aux record,
+// which the caller stores.
+__device__ inline uint32_t next_task(const KParams& p, int env, Env& e, int& task) {
+    const uint32_t ep = e.episode;
+    e.episode = ep + 1;
     if (p.sample_tasks) {  // CustomTasks.reset on the device: uniform choice over the table
         task = rng_task(p.sample_seed, (uint64_t)(p.env_base + env), (uint64_t)ep, p.n_tasks);
-        if (leader) p.env_task[env] = task;
     } else if (p.rt_enabled) {  // RandomTasks.sample_task on the device: the env's own row is regenerated
         task = env;
-        if (leader) p.env_task[env] = env;
     }
     return ep;
 }
@@ -330,55 +302,13 @@ __device__ inline void reset_rows_wave(const KParams& p, int env, int task, bool
     reinterpret_cast<uint4*>(p.hist + (size_t)env * HIST_ROW)[lane] = make_uint4(0, 0, 0, 0);
 }
 
-// obs of reset(): agentPos zeros, compass 0 (env.py:247-254)
-__device__ inline void write_reset_obs(const KParams& p, int env, const Env& e) {
-    float* ap = p.agent_pos + 5 * (size_t)env;
-    ap[0] = 0.f; ap[1] = 0.f; ap[2] = 0.f; ap[3] = 0.f; ap[4] = 0.f;
-    float* iv = p.inventory + 6 * (size_t)env;
-#pragma unroll
-    for (int i = 0; i < 6; i++) iv[i] = (float)inv_get(e.inv, i);
-    p.compass[env] = 0.f;
-}
-
-// obs of step(): env.py:281-289
-__device__ inline void write_step_obs(const KParams& p, int env, const Env& e) {
-    float* ap = p.agent_pos + 5 * (size_t)env;
-    st(ap + 0, (float)e.x); st(ap + 1, (float)e.y); st(ap + 2, (float)e.z); st(ap + 3, (float)e.pitch); st(ap + 4, (float)e.yaw);
-    float* iv = p.inventory + 6 * (size_t)env;
-#pragma unroll
-    for (int i = 0; i < 6; i++) st(iv + i, (float)inv_get(e.inv, i));
-    st(p.compass + env, (float)(e.yaw - 180.0));
-}
-
-// The same observation / pose stores by the FOUR lanes of an env's (first) quad: the CU's address pipe takes a
-// wavefront's store in 4 (dword) or 16 (dwordx4) cycles whether one lane of a quad is active or all four, so twelve
-// dword stores by the leader lane cost four times what three stores by all four lanes cost, and sixteen wavefronts
-// per CU queue there at the end of a launch.  Lane q: agent_pos[q] | agent_pos[4], compass, inventory[0], [1] |
-// inventory[2 + q].  Reset observations go the same way (same lane -> same address, so program order holds).
-__device__ __forceinline__ void store_obs_spread(const KParams& p, int env, int q, float a0, float a1, float a2, float a3, float a4,
-                                        float compass, const Env& e) {
-    float* ap = p.agent_pos + 5 * (size_t)env;
-    float* iv = p.inventory + 6 * (size_t)env;
-    const float i0 = (float)inv_get(e.inv, 0), i1 = (float)inv_get(e.inv, 1), i2 = (float)inv_get(e.inv, 2),
-                i3 = (float)inv_get(e.inv, 3), i4 = (float)inv_get(e.inv, 4), i5 = (float)inv_get(e.inv, 5);
-    st(ap + q, q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : a3);
-    float* pb = q == 0 ? ap + 4 : q == 1 ? p.compass + env : iv + (q - 2);
-    st(pb, q == 0 ? a4 : q == 1 ? compass : q == 2 ? i0 : i1);
-    st(iv + 2 + q, q == 0 ? i2 : q == 1 ? i3 : q == 2 ? i4 : i5);
-}
-__device__ __forceinline__ void write_step_obs_spread(const KParams& p, int env, int q, const Env& e) {
-    store_obs_spread(p, env, q, (float)e.x, (float)e.y, (float)e.z, (float)e.pitch, (float)e.yaw, (float)(e.yaw - 180.0), e);
-}
-__device__ __forceinline__ void write_reset_obs_spread(const KParams& p, int env, int q, const Env& e) {
-    store_obs_spread(p, env, q, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, e);
-}
-// pose: lane q < 3 stores the 16-byte piece q of the record
-__device__ __forceinline__ void env_store_pose_spread(double x, double y, double z, double yaw, double pitch, double vy, AgentRec* rec,
-                                                      int q) {
-    // (by value: a select between FIELDS of the env struct becomes a load from a selected address and parks the
-    // struct in scratch memory)
+// The agent record as its four 16-byte pieces, lane q of the env's (first) quad stores piece q: ONE store instruction
+// for the whole record.  (By value: a select between FIELDS of the env struct becomes a load from a selected address
+// and parks the struct in scratch memory.)
+__device__ __forceinline__ uint4 agent_piece(int q, double x, double y, double z, double yaw, double pitch, double vy, const uint4& piece3) {
     const double a = q == 0 ? x : q == 1 ? z : pitch, b = q == 0 ? y : q == 1 ? yaw : vy;
-    st(reinterpret_cast<vd2*>(rec) + q, vd2{a, b});
+    const uint4 pose = make_uint4((uint32_t)__double2loint(a), (uint32_t)__double2hiint(a), (uint32_t)__double2loint(b), (uint32_t)__double2hiint(b));
+    return q == 3 ? piece3 : pose;
 }
 
 struct CellChange {
@@ -484,7 +414,7 @@ __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* 
     if (a.want_sight) {
         if (a.add) {
             if (h.hit && h.have_prev) {
-                if (inv_get(e.inv, e.active - 1) > 0 && build_zone_i(h.px, h.py, h.pz)) {
+                if (inv_get(e, e.active - 1) > 0 && build_zone_i(h.px, h.py, h.pz)) {
                     const double x = e.x, z = e.z;
                     const double y = e.y - 1.0 + PAD;  // y - (PLAYER_HEIGHT - 1) + Agent.PAD
                     const double bx = (double)h.px - 0.5, by = (double)h.py, bz = (double)h.pz - 0.5;
@@ -495,7 +425,7 @@ __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* 
                         ch.bit = occ_bit_hbm(h.px, h.py, h.pz);
                         ch.old_val = 0;  // `previous` is never occupied
                         ch.new_val = e.active;
-                        e.inv = inv_add(e.inv, e.active - 1, -1);
+                        inv_add(e, e.active - 1, -1);
                     }
                 }
             }
@@ -544,7 +474,7 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
 __device__ inline void finish_break(Env& e, const CellChange& ch) {
     if (ch.idx >= 0 && ch.new_val == 0) {
         const int texture = old_colour(ch);
-        if (texture >= 1 && texture <= 6) e.inv = inv_add(e.inv, texture - 1, 1);
+        if (texture >= 1 && texture <= 6) inv_add(e, texture - 1, 1);
     }
 }
 
@@ -636,17 +566,17 @@ __device__ inline int syn_size_delta(const CellChange& ch, int start_val) {
 struct TailParams {
     int max_steps, size_reward, autoreset;
     double right_scale, wrong_scale;
-    float* reward;
-    uint8_t* done;
+    OutRec* out;
     AgentRec* agent;
+    AuxRec* aux;
     unsigned long long* stats;
     uint32_t* occ;
 };
 __device__ inline TailParams tail_params(const KParams& p) {
-    TailParams t = {p.max_steps, p.size_reward, p.autoreset, p.right_scale, p.wrong_scale, p.reward, p.done, p.agent, p.stats, p.occ};
+    TailParams t = {p.max_steps, p.size_reward, p.autoreset, p.right_scale, p.wrong_scale, p.out, p.agent, p.aux, p.stats, p.occ};
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(t.max_steps), "+s"(t.size_reward), "+s"(t.autoreset), "+s"(t.right_scale), "+s"(t.wrong_scale),
-                 "+s"(t.reward), "+s"(t.done), "+s"(t.agent), "+s"(t.stats), "+s"(t.occ));
+                 "+s"(t.out), "+s"(t.agent), "+s"(t.aux), "+s"(t.stats), "+s"(t.occ));
 #endif
     return t;
 }
@@ -1045,21 +975,23 @@ __device__ inline void write_trajectory(const KParams& p, const ActIn& a, int en
         rec[3] = __float_as_uint((float)e.pitch); rec[4] = __float_as_uint((float)e.yaw);
         rec[5] = __float_as_uint((float)o.reward);
         rec[6] = __float_as_uint((float)(e.yaw - 180.0));
-        rec[7] = ch.idx < 0 ? 0xffffffffu : ((uint32_t)ch.idx | (((uint32_t)ch.new_val & 0xffu) << 16));
-        rec[8] = (uint32_t)(e.inv & 0xffffffffull);
-        rec[9] = (uint32_t)((e.inv >> 32) & 0xffffull) | ((o.done ? 1u : 0u) << 16) | ((uint32_t)MODE << 24);
-        for (int i = 10; i < 16; i++) rec[i] = 0;
+        rec[7] = e.inv01; rec[8] = e.inv23; rec[9] = e.inv45;
+        uint32_t tag = (uint32_t)MODE;
+        for (int i = 11; i < 16; i++) rec[i] = 0;
         if (MODE == MODE_WALK) {
-            rec[10] = (uint32_t)a.actions[env];
+            rec[11] = (uint32_t)a.actions[env];
         } else if (MODE == MODE_FLY) {
-            for (int i = 0; i < 3; i++) rec[10 + i] = __float_as_uint(a.movement[3 * (size_t)env + i]);
-            for (int i = 0; i < 2; i++) rec[13 + i] = __float_as_uint(a.camera[2 * (size_t)env + i]);
-            rec[15] = ((uint32_t)a.inventory[env] & 0xffu) | (((uint32_t)a.placement[env] & 0xffu) << 8);
+            for (int i = 0; i < 3; i++) rec[11 + i] = __float_as_uint(a.movement[3 * (size_t)env + i]);
+            for (int i = 0; i < 2; i++) rec[14 + i] = __float_as_uint(a.camera[2 * (size_t)env + i]);
+            const int inv = a.inventory[env], plc = a.placement[env];   // as executed: a rejected id runs as 0, placement 1 / 2 / other
+            tag |= ((unsigned)inv > 6u ? 0u : (uint32_t)inv << 2) | ((plc == 1 ? 1u : plc == 2 ? 2u : 0u) << 5);
         } else {
             const uint2 bw = *reinterpret_cast<const uint2*>(a.buttons + 8 * (size_t)env);
-            rec[10] = bw.x; rec[11] = bw.y;
-            for (int i = 0; i < 2; i++) rec[12 + i] = __float_as_uint(a.camera[2 * (size_t)env + i]);
+            rec[11] = bw.x; rec[12] = bw.y;
+            for (int i = 0; i < 2; i++) rec[13 + i] = __float_as_uint(a.camera[2 * (size_t)env + i]);
         }
+        const uint32_t change = ch.idx < 0 ? 0xffffu : ((uint32_t)ch.idx | (((uint32_t)ch.new_val & 7u) << 11));
+        rec[10] = change | ((o.done ? 1u : 0u) << 16) | (tag << 24);
         uint4* dst = reinterpret_cast<uint4*>(p.traj + (((size_t)env * 2 + (ep & 1)) * p.traj_cap + (step - 1)) * IGW_TRAJ_BYTES);
 #pragma unroll
         for (int i = 0; i < 4; i++) dst[i] = make_uint4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
@@ -1088,20 +1020,21 @@ template <int OFFSET = 0>
 __device__ inline const KParams& kernarg_again(const KParams& p) { return p; }
 #endif
 
-// The end of a step: reward / done, the in-step reset, the last stores.
+// The end of a step: reward / done, the in-step reset, the last stores.  size_in: SizeReward.size as the step loaded it
+// (the aux record goes back to memory only when something in it changed).
 template <int GS, int MODE, bool EXTRA>
 __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn& a, BlockShared<GS>& sh, int wave, int env,
                                  bool active, Env& e, const CellChange& ch, int task, int env_max_int, int size_new, int mi,
                                  bool need, bool changed, int8_t* grid_g, const uint32_t* occ_s, bool boost,
-                                 [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok, const TailParams& tp) {
+                                 [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok, const TailParams& tp, int size_in) {
     const StepOut o = finish_step(tp, e, env_max_int, size_new, mi);
     const bool do_reset = active && o.done && tp.autoreset;
-    uint32_t ep = 0;
+    uint32_t ep = e.episode;
     const int task_old = task;
     int generated_size = -1;
     bool has_start = false;
     if (do_reset) {
-        ep = next_task(p, env, G.gl == 0, task);  // the next episode's task (task generators on the device)
+        ep = next_task(p, env, e, task);  // the next episode's task (task generators on the device)
         // (an episode that ends early -- target completed -- or a task that was only just chosen: fetched now)
         if (!pre_ok) rm = load_reset_meta(p.task_meta + task);
         has_start = !p.rt_enabled && rm.has_start;
@@ -1119,30 +1052,32 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
 #endif
     if (!active) return;
     if constexpr (EXTRA) {
-        if (p.traj && env < p.traj_n && G.gl == 0) {
-            const uint32_t ep_now = do_reset ? ep : __hip_atomic_load(p.episode + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            write_trajectory<MODE>(p, a, env, task_old, ep_now, e, ch, o, do_reset, task);
-        }
+        if (p.traj && env < p.traj_n && G.gl == 0) write_trajectory<MODE>(p, a, env, task_old, ep, e, ch, o, do_reset, task);
     }
+    const bool aux_dirty = changed || do_reset || e.size != size_in;
     if (do_reset) reset_env_regs(e, rm, false, generated_size);
-    if (G.gl == 0) {
-        if (ch.idx >= 0 && !do_reset) {
-            grid_g[ch.idx] = (int8_t)ch.new_val;
-            tp.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = ch.occ_word;
-        }
-        if (!IGW_DIAG_FLAG(p, 16)) {  // diag 16: what the output stores cost
-            st(tp.reward + env, (float)o.reward);
-            st(tp.done + env, (uint8_t)(o.done ? 1 : 0));
-            if (GS < 4 && do_reset) write_reset_obs(p, env, e);
-        }
-        if (GS < 4 && do_reset) env_store_pose(e, tp.agent + env);
-        env_store_counters(e, tp.agent + env);
+    if (G.gl == 0 && ch.idx >= 0 && !do_reset) {
+        grid_g[ch.idx] = (int8_t)ch.new_val;
+        tp.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = ch.occ_word;
     }
-    if constexpr (GS >= 4) {  // the reset's observations and pose go the way the step's went (lane -> address)
+    if constexpr (GS >= 4) {
+        // the reset's record and observations go the way the step's went (same lane -> same address: program order)
         if (do_reset && G.gl < 4) {
-            if (!IGW_DIAG_FLAG(p, 16)) write_reset_obs_spread(p, env, G.gl, e);
-            if (G.gl < 3) env_store_pose_spread(e.x, e.y, e.z, e.yaw, e.pitch, e.vy, tp.agent + env, G.gl);
+            st4(reinterpret_cast<uint4*>(tp.agent + env) + G.gl, agent_piece(G.gl, e.x, e.y, e.z, e.yaw, e.pitch, e.vy, env_pack_piece3(e)));
+            if (G.gl < 3 && !IGW_DIAG_FLAG(p, 16)) st4(reinterpret_cast<uint4*>(tp.out + env) + G.gl, out_piece_reset(e, G.gl));
         }
+        // reward + done (lane 3) and -- when it changed -- the aux record (lane 0): two arrays, ONE store instruction
+        const bool is_res = G.gl == 3;
+        const uint4 v = is_res ? out_piece_result((float)o.reward, o.done) : env_pack_aux(e, task);
+        void* dst = is_res ? (void*)(reinterpret_cast<uint4*>(tp.out + env) + 3) : (void*)(tp.aux + env);
+        if ((is_res && !IGW_DIAG_FLAG(p, 16)) || (G.gl == 0 && aux_dirty)) st4(dst, v);
+    } else if (G.gl == 0) {
+        if (do_reset) env_store(e, tp.agent + env);
+        if (!IGW_DIAG_FLAG(p, 16)) {
+            if (do_reset) out_store(tp.out + env, e, true, (float)o.reward, o.done);
+            else st4(reinterpret_cast<uint4*>(tp.out + env) + 3, out_piece_result((float)o.reward, o.done));
+        }
+        if (aux_dirty) aux_store(e, task, tp.aux + env);
     }
     {   // the wave's counters: one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
         const uint64_t m_need = __ballot(need && G.gl == 0), m_cell = __ballot(ch.idx >= 0 && G.gl == 0),
@@ -1163,10 +1098,10 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
 // so the plain kernel carries neither their code nor their registers).  Narrow groups pack so many envs per block
 // that LDS (one occupancy row per env) caps them at 2-3 blocks per CU anyway.
 template <int GS, int MODE, bool EXTRA, bool EXACT = false>
-__global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const uint32_t* h_occ, const AgentRec* h_agent, const int32_t* h_env_task,
+__global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const uint32_t* h_occ, const AgentRec* h_agent, const AuxRec* h_aux,
                                                                         const void* h_a0, const void* h_a1, const void* h_a2, const void* h_a3,
                                                                         KParams p, ActIn a) {
-    // The seven leading arguments are what the input burst needs -- occupancy rows, agent records, task indices, the
+    // The seven leading arguments are what the input burst needs -- occupancy rows, agent records, aux records, the
     // action buffers (walking: h_a0 = actions; Dict: buttons, camera; flying: movement, camera, inventory, placement)
     // and, where a slot is free (h_a3, walking and Dict), the number of envs.  The library is built with
     // -amdgpu-kernarg-preload-count=7: they arrive in scalar registers with the wavefront, and the first loads of the
@@ -1197,17 +1132,23 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // issued before the first wait: one memory round trip.
     OccStage<GS> occ_in = {};
     if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);  // diag 32: what the occupancy rows cost in the load burst
-    int task = h_env_task[env_r];
     // The agent record: with four or more lanes per env, lane q of a quad fetches the 16-byte piece q and the quad
     // hands the pieces round by DPP after the wait -- ONE dwordx4 per lane instead of four.  (All four lanes reading
     // the whole record is one cache line per env either way, but the CU's address pipe handles a wavefront's
     // dwordx4 in 16 cycles whatever the addresses, and sixteen wavefronts per CU queue up behind one another there:
     // the input burst of a wavefront was 48 + 64 + 8 of those cycles, the record more than half of it.)
+    // The aux record (episode ints, task row, episode counter) likewise: lane q fetches its dword q.
     constexpr bool REC_SPREAD = GS >= 4;
     AgentRec rec;
-    uint4 rec_piece = make_uint4(0, 0, 0, 0);
-    if constexpr (REC_SPREAD) rec_piece = reinterpret_cast<const uint4*>(h_agent + env_r)[G.gl & 3];
-    else rec = h_agent[env_r];  // every lane of the group reads the same 64 B line (one request)
+    uint4 rec_piece = make_uint4(0, 0, 0, 0), aux = make_uint4(0, 0, 0, 0);
+    uint32_t aux_w = 0;
+    if constexpr (REC_SPREAD) {
+        rec_piece = reinterpret_cast<const uint4*>(h_agent + env_r)[G.gl & 3];
+        aux_w = reinterpret_cast<const uint32_t*>(h_aux + env_r)[G.gl & 3];
+    } else {
+        rec = h_agent[env_r];  // every lane of the group reads the same 64 B line (one request)
+        aux = *reinterpret_cast<const uint4*>(h_aux + env_r);
+    }
     constexpr bool FLY_SPREAD = MODE == MODE_FLY && GS >= 4;
     const ActIn ah = {(const int32_t*)h_a0, (const float*)h_a0, (const float*)h_a1, (const int32_t*)h_a2, (const int32_t*)h_a3,
                       (const uint8_t*)h_a0};   // (the fields of the mode's own action space are the valid ones)
@@ -1220,20 +1161,20 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // ... and ONE wait: the empty statement below takes a register of every load above as an operand, and the
     // occupancy words as in-out operands, so every load is issued before it and the LDS writes of the occupancy row
     // come after it.  (Without it the compiler waited for the occupancy row, wrote it to LDS, and only then issued
-    // the loads of the agent record, the task index and the action: two memory round trips, 2.6 K cycles, at the head
+    // the loads of the agent record, the aux record and the action: two memory round trips, 2.6 K cycles, at the head
     // of every wavefront, in round 2 as well.)
     if constexpr (GS == 4) {
         uint32_t &o0 = occ_in.v[0].x, &o1 = occ_in.v[1].x, &o2 = occ_in.v[2].x;
         if constexpr (MODE == MODE_WALK)
-            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.action), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(aux_w), "v"(ra.action), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
         else if constexpr (MODE == MODE_FLY)
-            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.w1), "v"(ra.w2), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(aux_w), "v"(ra.w1), "v"(ra.w2), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
         else
-            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(task), "v"(ra.buttons.x), "v"(ra.f[3]), "v"(ra.f[4]), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(aux_w), "v"(ra.buttons.x), "v"(ra.f[3]), "v"(ra.f[4]), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
     }
 #endif
     occ_commit_var<GS>(G, occ_in, occ_s);
-    if constexpr (REC_SPREAD) {  // piece 0: x, y | 1: z, yaw | 2: pitch, vy | 3: counters, inv_pack (include/igw.h)
+    if constexpr (REC_SPREAD) {  // piece 0: x, y | 1: z, yaw | 2: pitch, vy | 3: inventory, step_no, pack (include/igw.h)
         uint32_t w[16];
         const int px = (int)rec_piece.x, py = (int)rec_piece.y, pz = (int)rec_piece.z, pw = (int)rec_piece.w;
         w[0] = (uint32_t)dpp_quad<QUAD_BCAST0>(px); w[1] = (uint32_t)dpp_quad<QUAD_BCAST0>(py);
@@ -1245,9 +1186,13 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
         w[12] = (uint32_t)dpp_quad<QUAD_BCAST3>(px); w[13] = (uint32_t)dpp_quad<QUAD_BCAST3>(py);
         w[14] = (uint32_t)dpp_quad<QUAD_BCAST3>(pz); w[15] = (uint32_t)dpp_quad<QUAD_BCAST3>(pw);
         __builtin_memcpy(&rec, w, sizeof(rec));
+        aux = make_uint4((uint32_t)dpp_quad<QUAD_BCAST0>((int)aux_w), (uint32_t)dpp_quad<QUAD_BCAST1>((int)aux_w),
+                         (uint32_t)dpp_quad<QUAD_BCAST2>((int)aux_w), (uint32_t)dpp_quad<QUAD_BCAST3>((int)aux_w));
     }
     Env e;
-    env_unpack(e, rec);
+    env_unpack(e, rec, aux);
+    int task = (int)aux.z;
+    const int size_in = e.size;
     // an episode that reaches max_steps in this step is reset inside the kernel: what the reset needs of its task's
     // metadata row is fetched now (ResetMeta; with a task generator on the next task is not known yet)
     const bool ends = p.autoreset && e.step_no + 1 >= p.max_steps;
@@ -1330,13 +1275,16 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // wave (issued from tail_step instead: +0.7 % launch time, same-box A/B).  (A reset at the end of this step
     // overwrites them: same lane, same addresses, program order.)
     if constexpr (GS >= 4) {
-        if (active && G.gl < 4) {
-            if (!IGW_DIAG_FLAG(p, 16)) write_step_obs_spread(p, env, G.gl, e);
-            if (G.gl < 3) env_store_pose_spread(e.x, e.y, e.z, e.yaw, e.pitch, e.vy, p.agent + env, G.gl);
+        if (active && G.gl < 4) {   // the whole agent record in ONE store instruction, the observations in a second
+            st4(reinterpret_cast<uint4*>(p.agent + env) + G.gl, agent_piece(G.gl, e.x, e.y, e.z, e.yaw, e.pitch, e.vy, env_pack_piece3(e)));
+            if (G.gl < 3 && !IGW_DIAG_FLAG(p, 16)) st4(reinterpret_cast<uint4*>(p.out + env) + G.gl, out_piece_step(e, G.gl));
         }
     } else if (writer) {
-        if (!IGW_DIAG_FLAG(p, 16)) write_step_obs(p, env, e);
-        env_store_pose(e, p.agent + env);
+        env_store(e, p.agent + env);
+        if (!IGW_DIAG_FLAG(p, 16)) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) st4(reinterpret_cast<uint4*>(p.out + env) + q, out_piece_step(e, q));
+        }
     }
     stamp(p, 4);
     const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch, start_val);
@@ -1354,7 +1302,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     stamp(p, 5);
     prio_at<true, 6>(boost);
     // (KParams sits behind the preloaded head arguments: kernarg_again reads it at that offset of the kernarg segment)
-    tail_step<GS, MODE, EXTRA>(G, kernarg_again<STEP_KERNARG_HEAD>(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp);
+    tail_step<GS, MODE, EXTRA>(G, kernarg_again<STEP_KERNARG_HEAD>(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp, size_in);
 }
 
 // T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
@@ -1371,9 +1319,10 @@ struct RolloutIO {
     const int32_t* placement;
 };
 // __launch_bounds__(BLOCK, 3): left alone the loop keeps 196 registers live (2 waves per SIMD); three waves per SIMD
-// (168 registers, 5 spilled dwords) measured fastest: 6.1 G against 5.4 G; four (128, 39 spilled) 5.9 G.
+// (168 registers) measured fastest: 6.1 G against 5.4 G; four (128, 39 spilled) 5.9 G.  Groups of 16+ lanes serve
+// batches of at most 4,096 envs (one wavefront per SIMD): no bound worth a spill there.
 template <int GS, int MODE = MODE_WALK>
-__global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KParams p, long long T, unsigned long long seed,
+__global__ __launch_bounds__(BLOCK, ((GS == 4 || GS == 8) ? 3 : 2)) void rollout_kernel(KParams p, long long T, unsigned long long seed,
                                                         long long t0, long long env_offset, RolloutIO io) {
     __shared__ BlockShared<GS> sh;
     const Grp<GS> G;
@@ -1398,8 +1347,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
     const TaskMeta* meta = nullptr;
     int8_t* grid_g = p.grid + (size_t)(active ? env : 0) * STRIDE;
     if (active) {
-        env_load(e, p.agent + env);
-        task = p.env_task[env];
+        task = env_load(e, p.agent + env, p.aux + env);
         meta = p.task_meta + task;
         has_start = meta->has_start != 0;
         env_max_int = meta->env_max_int;
@@ -1484,7 +1432,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
         uint32_t ep = 0;
         int generated_size = -1;
         if (active && do_reset) {
-            ep = next_task(p3, env, G.gl == 0, task);
+            ep = next_task(p3, env, e, task);
             meta = p3.task_meta + task;
             has_start = !p3.rt_enabled && meta->has_start != 0;
             env_max_int = p3.rt_enabled ? 0 : meta->env_max_int;
@@ -1503,11 +1451,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 3 : 2)) void rollout_kernel(KPara
     wave_sync();
     for (int w = G.gl; w < OCC_WORDS; w += GS) p.occ[(size_t)env * OCC_WORDS + w] = occ_s[OCC_VAR0 + w];
     if (G.gl == 0) {
-        p.reward[env] = (float)o.reward;
-        p.done[env] = o.done ? 1 : 0;
-        if (last_reset) write_reset_obs(p, env, e);
-        else write_step_obs(p, env, e);
+        out_store(p.out + env, e, last_reset, (float)o.reward, o.done);
         env_store(e, p.agent + env);
+        aux_store(e, task, p.aux + env);
         if (n_changed) stat_add(p.stats, IGW_STAT_CHANGED, n_changed);
         if (n_resets) stat_add(p.stats, IGW_STAT_RESETS, n_resets);
         if (n_updates) stat_add(p.stats, IGW_STAT_RESCANS, n_updates);
@@ -1522,9 +1468,8 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(KParams p, const uint8_t* 
     if (env >= p.n_envs) return;
     if (mask && !mask[env]) return;
     Env e;
-    env_load(e, p.agent + env);
-    int task = p.env_task[env];
-    const uint32_t ep = next_task(p, env, __lane_id() == 0, task);
+    int task = env_load(e, p.agent + env, p.aux + env);
+    const uint32_t ep = next_task(p, env, e, task);
     const TaskMeta* meta = p.task_meta + task;
     int generated_size = -1;
     bool has_start = false;
@@ -1533,10 +1478,9 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(KParams p, const uint8_t* 
     reset_rows_wave(p, env, task, has_start, nullptr);
     reset_env_regs(e, meta, keep_size != 0, generated_size);
     if (__lane_id() == 0) {
-        write_reset_obs(p, env, e);
-        p.reward[env] = 0.f;
-        p.done[env] = 0;
+        out_store(p.out + env, e, true, 0.f, false);
         env_store(e, p.agent + env);
+        aux_store(e, task, p.aux + env);
         if (p.traj && env < p.traj_n)  // the new episode's slot of the log starts empty
             *reinterpret_cast<int4*>(p.traj_heads + ((size_t)env * 2 + ((ep + 1) & 1)) * 4) = make_int4(task, 0, (int)(ep + 1), 0);
     }
@@ -1582,10 +1526,16 @@ __global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int fir
     else zero_row_lds_wave(S);
     if (full_grid) row_to_lds_wave(F, full_grid + (size_t)i * STRIDE);
     wave_sync();
-    {   // block ids are 0..7 (env.py:85: Box(low=-1, high=7)); a cell with another id can never vote (colour index)
+    {   // block ids are 0..7 (env.py:85: Box(low=-1, high=7)): a cell with another id is read as empty, so that target
+        // size, bounding boxes and colour index of the row stay consistent, and the row is counted
         bool odd = false;
-        for (int c = lane; c < CELLS; c += WAVE) odd = odd || (unsigned)T[c] > 7u || (unsigned)S[c] > 7u;
+        for (int c = lane; c < CELLS; c += WAVE) {
+            if ((unsigned)T[c] > 7u) { T[c] = 0; odd = true; }
+            if ((unsigned)S[c] > 7u) { S[c] = 0; odd = true; }
+            if (full_grid && (unsigned)F[c] > 7u) { F[c] = 0; odd = true; }
+        }
         if (__ballot(odd) && lane == 0) stat_add(p.stats, IGW_STAT_BAD_TASK, 1);
+        wave_sync();
     }
     // GridWorld.max_int at reset = user task on the starting grid (env.py:241); the user task's
     // admissible set comes from full_grid when given (task.py:63-66), or is [(0,0)] if not invariant
@@ -1668,7 +1618,7 @@ __global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int fir
             m.bbox[4 * k + 2] = (int8_t)((bb_syn[k] >> 16) & 0xff);
             m.bbox[4 * k + 3] = (int8_t)((bb_syn[k] >> 24) & 0xff);
         }
-        for (int k = 0; k < 6; k++) m.inv_init[k] = (int8_t)(20 - cnt[k]);
+        for (int k = 0; k < 6; k++) m.inv_init[k] = (int16_t)(20 - cnt[k]);  // env.py:243-246: unbounded in the reference, >= -1069 here
         m.has_start = nnz_s != 0;
         const_cast<TaskMeta*>(p.task_meta)[task] = m;
     }
@@ -1848,7 +1798,7 @@ int igw_create(const igw_config* cfg, igw_ctx** out) {
 int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t n_tasks) {
     if (!ctx) return fail(IGW_ERR_INVALID, "igw_set_task_sampling: null context");
     if (enabled) {
-        if (!ctx->bound || !ctx->kp.episode) return fail(IGW_ERR_UNBOUND, "igw_set_task_sampling: needs bound buffers with igw_buffers.episode");
+        if (!ctx->bound) return fail(IGW_ERR_UNBOUND, "igw_set_task_sampling: buffers not bound");
         if (n_tasks > ctx->cfg.num_tasks) return fail(IGW_ERR_INVALID, "igw_set_task_sampling: n_tasks exceeds the task table");
         if (ctx->kp.rt_enabled) return fail(IGW_ERR_INVALID, "igw_set_task_sampling: the RandomTasks generator is enabled on this context");
     }
@@ -1865,7 +1815,7 @@ int igw_set_random_tasks(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t m
         ctx->kp.rt_enabled = 0;
         return IGW_OK;
     }
-    if (!ctx->bound || !ctx->kp.episode) return fail(IGW_ERR_UNBOUND, "igw_set_random_tasks: needs bound buffers with igw_buffers.episode");
+    if (!ctx->bound) return fail(IGW_ERR_UNBOUND, "igw_set_random_tasks: buffers not bound");
     if (ctx->cfg.num_tasks < ctx->cfg.num_envs) return fail(IGW_ERR_INVALID, "igw_set_random_tasks: needs one task row per env (num_tasks >= num_envs)");
     if (ctx->kp.sample_tasks) return fail(IGW_ERR_INVALID, "igw_set_random_tasks: task sampling is enabled on this context");
     if (max_blocks < 1 || height_levels < 1 || height_levels > IGW_GRID_Y || max_dist < 1 || num_colors < 1 || num_colors > 6)
@@ -1893,7 +1843,7 @@ int igw_set_trajectory_log(igw_ctx* ctx, void* records, int32_t* heads, int32_t 
         ctx->kp.traj_n = 0;
         return IGW_OK;
     }
-    if (!ctx->bound || !ctx->kp.episode) return fail(IGW_ERR_UNBOUND, "igw_set_trajectory_log: needs bound buffers with igw_buffers.episode");
+    if (!ctx->bound) return fail(IGW_ERR_UNBOUND, "igw_set_trajectory_log: buffers not bound");
     if (n_logged > ctx->cfg.num_envs || capacity < 1) return fail(IGW_ERR_INVALID, "igw_set_trajectory_log: n_logged / capacity out of range");
     if (((uintptr_t)records | (uintptr_t)heads) & 15) return fail(IGW_ERR_INVALID, "igw_set_trajectory_log: buffers must be 16-byte aligned");
     ctx->kp.traj = reinterpret_cast<uint8_t*>(records);
@@ -1921,34 +1871,26 @@ int igw_destroy(igw_ctx* ctx) {
 
 int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
     if (!ctx || !b) return fail(IGW_ERR_INVALID, "igw_bind_buffers: null argument");
-    if (!b->grid || !b->occ || !b->hist || !b->agent || !b->env_task || !b->task_target || !b->task_start ||
-        !b->task_start_occ || !b->task_meta || !b->agent_pos || !b->inventory || !b->compass || !b->reward || !b->done ||
-        !b->task_index)
+    if (!b->grid || !b->occ || !b->hist || !b->agent || !b->aux || !b->task_target || !b->task_start ||
+        !b->task_start_occ || !b->task_meta || !b->out || !b->task_index)
         return fail(IGW_ERR_INVALID, "igw_bind_buffers: a required buffer is null");
-    if (((uintptr_t)b->grid | (uintptr_t)b->occ | (uintptr_t)b->hist | (uintptr_t)b->agent | (uintptr_t)b->task_target |
-         (uintptr_t)b->task_start | (uintptr_t)b->task_start_occ | (uintptr_t)b->task_meta | (uintptr_t)b->task_index) & 15)
-        return fail(IGW_ERR_INVALID, "igw_bind_buffers: grid / occ / agent / task buffers must be 16-byte aligned");
+    if (((uintptr_t)b->grid | (uintptr_t)b->occ | (uintptr_t)b->hist | (uintptr_t)b->agent | (uintptr_t)b->aux | (uintptr_t)b->out |
+         (uintptr_t)b->task_target | (uintptr_t)b->task_start | (uintptr_t)b->task_start_occ | (uintptr_t)b->task_meta |
+         (uintptr_t)b->task_index) & 15)
+        return fail(IGW_ERR_INVALID, "igw_bind_buffers: grid / occ / hist / agent / aux / out / task buffers must be 16-byte aligned");
     KParams& k = ctx->kp;
     k.grid = b->grid;
     k.occ = b->occ;
     k.hist = b->hist;
     k.task_start_occ = b->task_start_occ;
     k.agent = reinterpret_cast<AgentRec*>(b->agent);
-    k.env_task = b->env_task;
+    k.aux = reinterpret_cast<AuxRec*>(b->aux);
     k.task_target = b->task_target;
     k.task_start = b->task_start;
     k.task_meta = reinterpret_cast<const TaskMeta*>(b->task_meta);
-    k.agent_pos = b->agent_pos;
-    k.inventory = b->inventory;
-    k.compass = b->compass;
-    k.reward = b->reward;
-    k.done = b->done;
+    k.out = reinterpret_cast<OutRec*>(b->out);
     k.stats = reinterpret_cast<unsigned long long*>(b->stats);
-    k.episode = b->episode;
     k.task_index = b->task_index;
-    if (!k.episode) {  // features keyed by the episode counter cannot outlive it
-        k.sample_tasks = 0; k.rt_enabled = 0; k.traj = nullptr; k.traj_heads = nullptr; k.traj_n = 0;
-    }
     ctx->bound = true;
     return IGW_OK;
 }
@@ -1976,11 +1918,11 @@ int igw_bind_buffers(igw_ctx* ctx, const igw_buffers* b) {
     do {                                                                                                           \
         if (ctx->kp.rt_enabled || ctx->kp.traj) {                                                                  \
             DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE, true>), dim3(env_blocks(ctx)), dim3(BLOCK), 0, \
-                                                    (hipStream_t)stream, ctx->kp.occ, ctx->kp.agent, ctx->kp.env_task,      \
+                                                    (hipStream_t)stream, ctx->kp.occ, ctx->kp.agent, ctx->kp.aux,      \
                                                     (const void*)(A0), (const void*)(A1), (const void*)(A2), (const void*)(A3), ctx->kp, a)); \
         } else {                                                                                                   \
             DISPATCH_GS(ctx->gs, hipLaunchKernelGGL((step_kernel<GS, MODE, false>), dim3(env_blocks(ctx)), dim3(BLOCK), 0, \
-                                                    (hipStream_t)stream, ctx->kp.occ, ctx->kp.agent, ctx->kp.env_task,      \
+                                                    (hipStream_t)stream, ctx->kp.occ, ctx->kp.agent, ctx->kp.aux,      \
                                                     (const void*)(A0), (const void*)(A1), (const void*)(A2), (const void*)(A3), ctx->kp, a)); \
         }                                                                                                          \
     } while (0)
@@ -2030,7 +1972,7 @@ int igw_step_flying(igw_ctx* ctx, const float* movement, const float* camera, co
     ActIn a = {nullptr, movement, camera, inventory, placement, nullptr};
     if (ctx->gs == 4 && !ctx->kp.rt_enabled && !ctx->kp.traj && ctx->kp.n_envs % (BLOCK / 4) == 0) {  // whole blocks: the EXACT variant
         hipLaunchKernelGGL((step_kernel<4, MODE_FLY, false, true>), dim3(env_blocks(ctx)), dim3(BLOCK), 0, (hipStream_t)stream, ctx->kp.occ,
-                           ctx->kp.agent, ctx->kp.env_task, (const void*)movement, (const void*)camera, (const void*)inventory,
+                           ctx->kp.agent, ctx->kp.aux, (const void*)movement, (const void*)camera, (const void*)inventory,
                            (const void*)placement, ctx->kp, a);
     } else {
         LAUNCH_STEP(MODE_FLY, movement, camera, inventory, placement);

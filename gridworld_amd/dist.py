@@ -29,14 +29,9 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if 'nccl' in backend and not os.environ.get('IGW_SHARE_GPU'):
             torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group(backend)
-        except Exception:  # noqa: BLE001 -- e.g. the nccl half cannot be built: the control plane alone will do
-            if 'nccl' not in backend:
-                raise
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            dist.init_process_group('gloo')
+        # (no silent re-initialisation when the mixed group cannot be built: a rank that fell back to gloo alone while
+        # its peers stayed in the mixed group would hang them; IGW_DIST_BACKEND=gloo selects the control plane only)
+        dist.init_process_group(backend)
     return rank, local_rank, world
 
 
@@ -78,7 +73,10 @@ class NodeBarrier:
         if self.rank == 0:
             os.unlink(self.path)  # the mappings keep it alive
 
-    def wait(self, timeout=120.0):
+    def wait(self, timeout=120.0, spins=2000):
+        """Spin for a few microseconds, then yield the CPU between polls (sched_yield, later short sleeps): with 8
+        ranks on a 16-CPU quota next to RCCL proxy / watchdog threads, an unbounded busy-wait can starve the very
+        rank it waits for."""
         if self.arr is None:
             return
         import time
@@ -86,10 +84,31 @@ class NodeBarrier:
         self.arr[64 * self.rank] = self.epoch
         others = [64 * r for r in range(self.world) if r != self.rank]
         t0 = time.perf_counter()
+        n = 0
         for o in others:
             while self.arr[o] < self.epoch:
-                if time.perf_counter() - t0 > timeout:
-                    raise RuntimeError('NodeBarrier: rank %d timed out waiting for the others' % self.rank)
+                n += 1
+                if n > spins:
+                    if n < 20 * spins:
+                        os.sched_yield()
+                    else:
+                        time.sleep(50e-6)
+                    if time.perf_counter() - t0 > timeout:
+                        raise RuntimeError('NodeBarrier: rank %d timed out waiting for the others' % self.rank)
+
+
+def shutdown():
+    """Closing barrier + destroy_process_group: every rank leaves together (a rank that falls off the end of main while
+    others are still inside a collective aborts them at teardown)."""
+    if dist.is_initialized():
+        try:
+            dist.barrier()
+        except Exception:  # noqa: BLE001 -- a peer already gone: still tear our side down
+            pass
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def _cpu_ok():
@@ -133,13 +152,25 @@ def gather_counts(value, device=None):
     return [int(o.item()) for o in out]
 
 
+def gather_floats(value, device=None):
+    """all_gather of one float64 per rank over the control plane (e.g. per-rank kernel time)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=_ctl_device(device))
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(o.item()) for o in out]
+
+
 def gather_counts_rccl(value, device):
     """The same gather over RCCL (CUDA tensors; xGMI between the GPUs of a node) -- the one place the data plane's
-    fabric is used at all.  Returns (values, how): if the RCCL collective raises (no nccl backend in the group, ranks
-    sharing one GPU, a broken fabric) the gather is repeated over gloo and `how` says so."""
+    fabric is used at all.  Returns (values, how).  Whether the RCCL collective worked is AGREED over the control plane
+    (an all-reduce(MIN) of an ok flag over gloo) before anybody falls back: a rank whose collective raised (a timeout on
+    one rank, say) must not enter the gloo gather alone while the others have already returned."""
     if not dist.is_initialized():
         return [int(value)], 'single process'
     if device is not None and device.type == 'cuda' and 'nccl' in str(dist.get_backend_config()):
+        vals, why = None, ''
         try:
             import datetime
             mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
@@ -147,10 +178,16 @@ def gather_counts_rccl(value, device):
             work = dist.all_gather(out, mine, async_op=True)
             work.wait(timeout=datetime.timedelta(seconds=float(os.environ.get('IGW_RCCL_TIMEOUT_S', '120'))))
             torch.cuda.synchronize(device)
-            return [int(o.item()) for o in out], 'rccl all_gather of one int64 per rank'
+            vals = [int(o.item()) for o in out]
         except Exception as e:  # noqa: BLE001
             why = (str(e).splitlines() or [type(e).__name__])[0][:160]
             if not _cpu_ok():
                 raise
-            return gather_counts(value), 'gloo (rccl all_gather failed: %s)' % why
+        if not _cpu_ok():
+            return vals, 'rccl all_gather of one int64 per rank'
+        ok = torch.tensor([1 if vals is not None else 0], dtype=torch.int64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # gloo
+        if int(ok.item()) == 1:
+            return vals, 'rccl all_gather of one int64 per rank'
+        return gather_counts(value), 'gloo (rccl all_gather failed on at least one rank%s)' % (': ' + why if why else '')
     return gather_counts(value), 'gloo'

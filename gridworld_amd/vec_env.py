@@ -62,23 +62,19 @@ class VecGridWorld:
         self.grid_buf = z((N, L.GRID_STRIDE), torch.int8)
         self.occ_buf = z((N, L.OCC_WORDS), torch.int32)
         self.hist_buf = z((N, L.HIST_ROW), torch.int16)
-        self.agent_buf = z((N, L.AGENT_BYTES), torch.uint8)
-        self.env_task = z((N,), torch.int32)
+        self.agent_buf = z((N, L.AGENT_BYTES), torch.uint8)   # pose, inventory, step_no, pack (include/igw.h)
+        self.aux_buf = z((N, L.AUX_BYTES), torch.uint8)       # size, prev_size, max_int, target_size, task, episode
+        self.out_buf = z((N, L.OUT_BYTES), torch.uint8)       # agentPos, inventory, compass, reward, done of every step
         self.task_target = z((T, L.GRID_STRIDE), torch.int8)
         self.task_start = z((T, L.GRID_STRIDE), torch.int8)
         self.task_start_occ = z((T, L.OCC_WORDS), torch.int32)
         self.task_meta = z((T, L.TASK_META_BYTES), torch.uint8)
         self.task_index = z((T, L.TASK_INDEX_BYTES), torch.uint8)   # colour index of the synthetic targets (include/igw.h)
-        self.agent_pos = z((N, 5), torch.float32)
-        self.inventory = z((N, 6), torch.float32)
-        self.compass = z((N,), torch.float32)
-        self.reward = z((N,), torch.float32)
-        self.done = z((N,), torch.uint8)
         self.stats_buf = z((L.STAT_STRIPES, 8), torch.int64)
-        self.episode = z((N,), torch.int32)  # episodes started per env (keys the device-side task generators)
+        self._make_views()
         # Agent.__init__ (core/world.py:12-29): time_int_steps = 2, active_block = BLUE, inventory 20
-        self.agent_buf[:, 56:62] = 20
-        self.agent_buf[:, 62] = 1 << 2  # u16 pack: time_int_steps code 0 (= 2), active_block 1, target_size 0
+        self.agent_buf.view(torch.int16)[:, 24:30] = 20
+        self.agent_buf[:, 62] = 1 << 2  # u16 pack: time_int_steps code 0 (= 2), active_block 1
         self.cfg = L.Config(dev.index or 0, N, T,
                             L.FLYING if self.flying else L.WALKING_DICT if self.walk_dict else L.WALKING_DISCRETE,
                             int(select_and_place), int(size_reward), self.max_steps, int(autoreset),
@@ -87,12 +83,10 @@ class VecGridWorld:
         self.env_index_base = int(env_index_base)
         self.ctx = C.c_void_p()
         L.check(self.lib.igw_create(C.byref(self.cfg), C.byref(self.ctx)), 'igw_create')
-        b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.occ_buf, self.hist_buf, self.agent_buf, self.env_task,
+        b = L.Buffers(*[t.data_ptr() for t in (self.grid_buf, self.occ_buf, self.hist_buf, self.agent_buf, self.aux_buf,
                                                 self.task_target, self.task_start, self.task_start_occ, self.task_meta,
-                                                self.agent_pos, self.inventory, self.compass, self.reward, self.done,
-                                                self.stats_buf, self.episode, self.task_index)])
+                                                self.task_index, self.out_buf, self.stats_buf)])
         L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(b)), 'igw_bind_buffers')
-        self.grid = torch.as_strided(self.grid_buf, (N, 9, 11, 11), (L.GRID_STRIDE, 121, 11, 1))
         self.user_target = None
         self._have_tasks = False
         self._tasks_filled = 0       # rows of the task table written so far (what task sampling draws from)
@@ -106,8 +100,26 @@ class VecGridWorld:
             self.lib.igw_destroy(ctx)
             self.ctx = None
 
+    def _make_views(self):
+        """The observation / result tensors of the env protocol (env.py:281-303) and the per-env task row / episode
+        counter as strided VIEWS of the records the kernels read and write (include/igw.h): nothing is copied."""
+        N = self.num_envs
+        f = self.out_buf.view(torch.float32)          # [N, 16]
+        self.agent_pos = f[:, 0:5]                    # x, y, z, pitch, yaw
+        self.inventory = f[:, 5:11]
+        self.compass = f[:, 11]
+        self.reward = f[:, 12]
+        self.done = self.out_buf[:, 52]
+        a = self.aux_buf.view(torch.int32)            # [N, 4]
+        self.env_task = a[:, 2]                       # row of the task table
+        self.episode = a[:, 3]                        # episodes started (keys the device-side task generators)
+        self.grid = torch.as_strided(self.grid_buf, (N, 9, 11, 11), (L.GRID_STRIDE, 121, 11, 1))
+        self._obs = {'agentPos': self.agent_pos, 'inventory': self.inventory, 'compass': self.compass.unsqueeze(1),
+                     'grid': self.grid}
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(self._dev_index))
 
     # ---- tasks (GridWorld.set_task / Task.__init__ / initialize_world) ----
     def set_tasks(self, targets, starts=None, full_grids=None, invariant=None, init_pose=None,
@@ -212,16 +224,29 @@ class VecGridWorld:
         L.check(self.lib.igw_set_trajectory_log(self.ctx, None, None, 0, 0), 'igw_set_trajectory_log')
         self._traj = None
 
+    _STATE_KEYS = ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'aux_buf', 'out_buf', 'task_target', 'task_start',
+                   'task_start_occ', 'task_meta', 'task_index', 'stats_buf')
+
     def state_dict(self):
         """Snapshot of the complete env state (tensors are cloned): resume / parity debugging."""
-        keys = ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'env_task', 'task_target', 'task_start',
-                'task_start_occ', 'task_meta', 'task_index', 'agent_pos', 'inventory', 'compass', 'reward', 'done',
-                'stats_buf', 'episode')
-        return {k: getattr(self, k).clone() for k in keys}
+        d = {k: getattr(self, k).clone() for k in self._STATE_KEYS}
+        d['abi_version'] = L.VERSION
+        return d
 
     def load_state_dict(self, state):
-        for k, v in state.items():
-            getattr(self, k).copy_(v)
+        """Restores a state_dict() snapshot.  The key set must be complete and of this ABI version: the step kernels
+        read every one of these buffers (a snapshot without the colour index, say, would load and then drift)."""
+        if state.get('abi_version') != L.VERSION:
+            raise ValueError(f'state_dict is of ABI version {state.get("abi_version")!r}, this build is version {L.VERSION}')
+        missing = [k for k in self._STATE_KEYS if k not in state]
+        extra = [k for k in state if k not in self._STATE_KEYS and k != 'abi_version']
+        if missing or extra:
+            raise ValueError(f'state_dict keys do not match: missing {missing}, unexpected {extra}')
+        for k in self._STATE_KEYS:
+            if tuple(state[k].shape) != tuple(getattr(self, k).shape):
+                raise ValueError(f'state_dict[{k!r}] has shape {tuple(state[k].shape)}, expected {tuple(getattr(self, k).shape)}')
+        for k in self._STATE_KEYS:
+            getattr(self, k).copy_(state[k])
         self._have_tasks = True
 
     # ---- reset / step ----
@@ -231,8 +256,7 @@ class VecGridWorld:
                              'using .set_tasks')
 
     def obs(self):
-        return {'agentPos': self.agent_pos, 'inventory': self.inventory, 'compass': self.compass.unsqueeze(1),
-                'grid': self.grid}
+        return self._obs.copy()
 
     def reset(self, mask=None, keep_size=False):
         self._need_tasks()
@@ -263,42 +287,69 @@ class VecGridWorld:
         """walking: int32 tensor [N]; walking with discretize=False: dict(buttons u8[N,8] = forward, back,
         left, right, jump, attack, use, hotbar -- or those eight keys separately -- and camera f32[N,2]);
         flying: dict(movement f32[N,3], camera f32[N,2], inventory i32[N], placement i32[N]).
-        Returns (obs, reward, done, info) of tensors living in HBM."""
-        self._need_tasks()
+        Returns (obs, reward, done, info) of tensors living in HBM -- views of the kernels' output record, the same
+        tensors every call.  Actions that already are contiguous device tensors of the kernel's dtypes (walking: int32
+        [N]; flying: float32 / int32) go straight to the C ABI: no conversion, no copy, one ctypes call."""
+        if not self._have_tasks:
+            self._need_tasks()
+        N = self.num_envs
+        if not (self.walk_dict or self.flying):
+            a = actions
+            if not (type(a) is torch.Tensor and a.dtype is torch.int32 and a.is_cuda and a.is_contiguous()):
+                a = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
+            if a.numel() != N:
+                raise ValueError(f'walking action needs {N} entries, got {a.numel()}')
+            rc = self.lib.igw_step_walking(self.ctx, a.data_ptr(), torch._C._cuda_getCurrentRawStream(self._dev_index))
+            if rc:
+                L.check(rc, 'igw_step_walking')
+            self._act_keep = a
+            return self._obs.copy(), self.reward, self.done, {}
         dev = self.device
-        if self.walk_dict or self.flying:
-            self._check_camera(actions['camera'])
+        self._check_camera(actions['camera'])
+
+        def dev_t(x, dt):   # already a contiguous device tensor of the kernel's dtype: as is
+            if type(x) is torch.Tensor and x.dtype is dt and x.is_cuda and x.is_contiguous():
+                return x
+            return torch.as_tensor(x, device=dev).to(dt).contiguous()
         if self.walk_dict:
             if 'buttons' in actions:
-                b = torch.as_tensor(actions['buttons'], device=dev).to(torch.uint8).reshape(self.num_envs, 8).contiguous()
+                b = dev_t(actions['buttons'], torch.uint8).reshape(-1, 8)
             else:  # the reference's Dict keys (env.py:60-70), one array per key
                 b = torch.stack([torch.as_tensor(np.asarray(actions[k]), device=dev).to(torch.uint8).reshape(-1)
                                  for k in ('forward', 'back', 'left', 'right', 'jump', 'attack', 'use', 'hotbar')],
                                 dim=1).contiguous()
-            if b.shape[0] != self.num_envs:
-                raise ValueError(f'walking Dict action needs {self.num_envs} rows of 8 buttons, got {tuple(b.shape)}')
-            cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).reshape(self.num_envs, 2).contiguous()
+            if b.shape[0] != N:
+                raise ValueError(f'walking Dict action needs {N} rows of 8 buttons, got {tuple(b.shape)}')
+            cam = dev_t(actions['camera'], torch.float32)
+            if cam.numel() != 2 * N:
+                raise ValueError(f'walking Dict action needs camera [{N},2], got {tuple(cam.shape)}')
             L.check(self.lib.igw_step_walking_dict(self.ctx, b.data_ptr(), cam.data_ptr(), self._stream()),
                     'igw_step_walking_dict')
             self._act_keep = (b, cam)
-        elif self.flying:
-            mv = torch.as_tensor(actions['movement'], device=dev).to(torch.float32).contiguous()
-            cam = torch.as_tensor(actions['camera'], device=dev).to(torch.float32).contiguous()
-            inv = torch.as_tensor(actions['inventory'], device=dev).to(torch.int32).contiguous()
-            pl = torch.as_tensor(actions['placement'], device=dev).to(torch.int32).contiguous()
-            N = self.num_envs
+        else:
+            mv, cam = dev_t(actions['movement'], torch.float32), dev_t(actions['camera'], torch.float32)
+            inv, pl = dev_t(actions['inventory'], torch.int32), dev_t(actions['placement'], torch.int32)
             if mv.numel() != 3 * N or cam.numel() != 2 * N or inv.numel() != N or pl.numel() != N:
                 raise ValueError(f'flying action needs movement [{N},3], camera [{N},2], inventory [{N}], placement [{N}]')
-            L.check(self.lib.igw_step_flying(self.ctx, mv.data_ptr(), cam.data_ptr(), inv.data_ptr(),
-                                             pl.data_ptr(), self._stream()), 'igw_step_flying')
+            rc = self.lib.igw_step_flying(self.ctx, mv.data_ptr(), cam.data_ptr(), inv.data_ptr(), pl.data_ptr(),
+                                          torch._C._cuda_getCurrentRawStream(self._dev_index))
+            if rc:
+                L.check(rc, 'igw_step_flying')
             self._act_keep = (mv, cam, inv, pl)
-        else:
-            a = torch.as_tensor(actions, device=dev).to(torch.int32).contiguous()
-            if a.numel() != self.num_envs:
-                raise ValueError(f'walking action needs {self.num_envs} entries, got {a.numel()}')
-            L.check(self.lib.igw_step_walking(self.ctx, a.data_ptr(), self._stream()), 'igw_step_walking')
-            self._act_keep = a
-        return self.obs(), self.reward, self.done, {}
+        return self._obs.copy(), self.reward, self.done, {}
+
+    # ---- a captured step loop (the loop of examples/run_env.py:18-26 as ONE HIP-graph launch) ----
+    def capture_steps(self, actions, record=False):
+        """Captures `for t in range(T): env.step(actions[t])` into a HIP graph and returns a StepGraph; replay() launches
+        the T steps in one call (no per-step host work at all), bit-identical to the eager loop.  `actions`: walking int32
+        device tensor [T, N]; flying dict of device tensors movement f32[T,N,3], camera f32[T,N,2], inventory i32[T,N],
+        placement i32[T,N]; walking Dict: buttons u8[T,N,8], camera f32[T,N,2].  The graph reads the action BUFFERS at
+        replay time: refill them in place (copy_) between replays to step with new actions.  record=True also copies
+        every step's output record (StepGraph.outs uint8 [T, N, 64]; .rewards / .dones are views of it).  Everything
+        that varies between replays lives in device memory (include/igw.h), so the samplers, auto-resets and the
+        episode log advance inside the replayed graph exactly as they do eagerly."""
+        self._need_tasks()
+        return StepGraph(self, actions, record)
 
     def step_walking_ptr(self, actions_i32):
         """Hot-loop variant: `actions_i32` is already a contiguous int32 device tensor [N]."""
@@ -403,12 +454,65 @@ class VecGridWorld:
         return out
 
     def task_state(self):
-        raw = self.agent_buf.cpu().numpy()
-        return {'step_no': raw[:, 48:50].copy().view(np.uint16)[:, 0].astype(np.int64),
-                'size': raw[:, 50:52].copy().view(np.int16)[:, 0].astype(np.int64),
-                'prev_size': (raw[:, 52:54].copy().view(np.uint16)[:, 0] & 0x7fff).astype(np.int64),
-                'dirty': (raw[:, 52:54].copy().view(np.uint16)[:, 0] >> 15).astype(np.int64),
-                'max_int': raw[:, 54:56].copy().view(np.int16)[:, 0].astype(np.int64)}
+        raw, aux = self.agent_buf.cpu().numpy(), self.aux_buf.cpu().numpy()
+        i16 = aux[:, :8].copy().view(np.int16).astype(np.int64)
+        return {'step_no': raw[:, 60:62].copy().view(np.uint16)[:, 0].astype(np.int64),
+                'inventory': raw[:, 48:60].copy().view(np.int16).astype(np.int64),
+                'size': i16[:, 0], 'prev_size': i16[:, 1] & 0x7fff, 'dirty': (i16[:, 1] >> 15) & 1,
+                'max_int': i16[:, 2], 'target_size': i16[:, 3]}
+
+    def set_step_no(self, step_no):
+        """Overwrites GridWorld.step_no of every env (int tensor / array [N]): de-synchronises the episodes of a batch."""
+        sn = torch.as_tensor(step_no, device=self.device).to(torch.int16).reshape(self.num_envs)
+        self.agent_buf.view(torch.int16)[:, 30] = sn
+
+
+class StepGraph:
+    """T captured env steps (VecGridWorld.capture_steps).  replay() launches them on the current stream and returns the
+    env's (obs, reward, done, info) views, which then hold the LAST step's values."""
+
+    def __init__(self, env, actions, record):
+        self.env = env
+        dev, N = env.device, env.num_envs
+
+        def need(x, dt, shape, what):
+            if not (type(x) is torch.Tensor and x.is_cuda and x.dtype is dt and x.is_contiguous() and tuple(x.shape[1:]) == shape):
+                raise ValueError(f'capture_steps: {what} must be a contiguous {dt} device tensor [T, {", ".join(map(str, shape))}]')
+            return x
+        if env.flying:
+            self.buffers = (need(actions['movement'], torch.float32, (N, 3), 'movement'), need(actions['camera'], torch.float32, (N, 2), 'camera'),
+                            need(actions['inventory'], torch.int32, (N,), 'inventory'), need(actions['placement'], torch.int32, (N,), 'placement'))
+            fn = env.lib.igw_step_flying
+        elif env.walk_dict:
+            self.buffers = (need(actions['buttons'], torch.uint8, (N, 8), 'buttons'), need(actions['camera'], torch.float32, (N, 2), 'camera'))
+            fn = env.lib.igw_step_walking_dict
+        else:
+            self.buffers = (need(actions, torch.int32, (N,), 'actions'),)
+            fn = env.lib.igw_step_walking
+        self.T = T = int(self.buffers[0].shape[0])
+        if T < 1 or any(b.shape[0] != T for b in self.buffers):
+            raise ValueError('capture_steps: every action buffer needs the same number of steps T >= 1')
+        self.outs = torch.zeros((T, N, L.OUT_BYTES), dtype=torch.uint8, device=dev) if record else None
+        ptrs = [tuple(b[t].data_ptr() for b in self.buffers) for t in range(T)]
+        self.graph = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        # (thread-local: other threads of the process -- an RCCL watchdog, a data loader -- may touch the runtime)
+        with torch.cuda.graph(self.graph, stream=cap, capture_error_mode='thread_local'):
+            h = C.c_void_p(cap.cuda_stream)
+            for t in range(T):
+                L.check(fn(env.ctx, *ptrs[t], h), 'step (capture)')
+                if record:
+                    self.outs[t].copy_(env.out_buf)
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        if record:
+            f = self.outs.view(torch.float32)
+            self.rewards, self.dones = f[:, :, 12], self.outs[:, :, 52]
+
+    def replay(self):
+        self.graph.replay()
+        env = self.env
+        return env._obs.copy(), env.reward, env.done, {}
 
 
 class SubBatch:
@@ -425,15 +529,13 @@ class SubBatch:
         self.cfg = cfg
         self.ctx = C.c_void_p()
         L.check(self.lib.igw_create(C.byref(cfg), C.byref(self.ctx)), 'igw_create')
-        per_env = (parent.grid_buf, parent.occ_buf, parent.hist_buf, parent.agent_buf, parent.env_task)
-        shared = (parent.task_target, parent.task_start, parent.task_start_occ, parent.task_meta)
-        outs = (parent.agent_pos, parent.inventory, parent.compass, parent.reward, parent.done)
-        self.stats_buf = torch.zeros_like(parent.stats_buf)
-        ptrs = [t[lo:lo + n].data_ptr() for t in per_env] + [t.data_ptr() for t in shared] + \
-               [t[lo:lo + n].data_ptr() for t in outs] + [self.stats_buf.data_ptr(), parent.episode[lo:lo + n].data_ptr(),
-                                                          parent.task_index.data_ptr()]
-        L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(L.Buffers(*ptrs))), 'igw_bind_buffers')
         sl = slice(lo, lo + n)
+        self.stats_buf = torch.zeros_like(parent.stats_buf)
+        rows = lambda t: t[sl].data_ptr()  # noqa: E731
+        ptrs = [rows(parent.grid_buf), rows(parent.occ_buf), rows(parent.hist_buf), rows(parent.agent_buf), rows(parent.aux_buf),
+                parent.task_target.data_ptr(), parent.task_start.data_ptr(), parent.task_start_occ.data_ptr(),
+                parent.task_meta.data_ptr(), parent.task_index.data_ptr(), rows(parent.out_buf), self.stats_buf.data_ptr()]
+        L.check(self.lib.igw_bind_buffers(self.ctx, C.byref(L.Buffers(*ptrs))), 'igw_bind_buffers')
         self.agent_pos, self.inventory = parent.agent_pos[sl], parent.inventory[sl]
         self.compass, self.reward, self.done = parent.compass[sl], parent.reward[sl], parent.done[sl]
         self.grid = parent.grid[sl]

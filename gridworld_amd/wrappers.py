@@ -68,32 +68,34 @@ class EpisodeLogger:
     def _decode(self, env, slot, task, length):
         np, v = self.np, self.vec
         from . import _lib as L
-        raw = self.records[env, slot, :length].cpu().numpy()
+        raw = self.records[env, slot, :length].cpu().numpy()   # record layout: include/igw.h (igw_set_trajectory_log)
         f32 = raw[:, :28].copy().view(np.float32).reshape(length, 7)
-        change = raw[:, 28:32].copy().view(np.int32)[:, 0]
+        inv = raw[:, 28:40].copy().view(np.int16).reshape(length, 6)
+        change = raw[:, 40:42].copy().view(np.uint16)[:, 0].astype(np.int64)
+        tag = raw[:, 43].astype(np.int64)
         meta = v.task_meta[task].cpu().numpy()
-        inv0 = meta[64:70].view(np.int8).astype(np.float32)
+        inv0 = meta[64:76].view(np.int16).astype(np.float32)
         grid0 = v.task_start[task, :L.CELLS].cpu().numpy().astype(np.int32).reshape(9, 11, 11)
         grids = np.empty((length + 1, 9, 11, 11), np.int32)
         grids[0] = grid0
         for t in range(length):
             grids[t + 1] = grids[t]
-            if change[t] != -1:
-                grids[t + 1].reshape(-1)[change[t] & 0xffff] = np.int8((change[t] >> 16) & 0xff)
-        space = int(raw[0, 39]) if length else 0
+            if change[t] != 0xffff:
+                grids[t + 1].reshape(-1)[change[t] & 0x7ff] = (change[t] >> 11) & 7
+        space = int(tag[0] & 3) if length else 0
         if space == 0:
-            actions = raw[:, 40:44].copy().view(np.int32)[:, 0]
+            actions = raw[:, 44:48].copy().view(np.int32)[:, 0]
         elif space == 1:
-            actions = {'movement': raw[:, 40:52].copy().view(np.float32).reshape(length, 3),
-                       'camera': raw[:, 52:60].copy().view(np.float32).reshape(length, 2),
-                       'inventory': raw[:, 60].astype(np.int32), 'placement': raw[:, 61].astype(np.int32)}
+            actions = {'movement': raw[:, 44:56].copy().view(np.float32).reshape(length, 3),
+                       'camera': raw[:, 56:64].copy().view(np.float32).reshape(length, 2),
+                       'inventory': ((tag >> 2) & 7).astype(np.int32), 'placement': ((tag >> 5) & 3).astype(np.int32)}
         else:
-            actions = {'buttons': raw[:, 40:48].copy(), 'camera': raw[:, 48:56].copy().view(np.float32).reshape(length, 2)}
+            actions = {'buttons': raw[:, 44:52].copy(), 'camera': raw[:, 52:60].copy().view(np.float32).reshape(length, 2)}
         zeros = np.zeros((1, 5), np.float32)
         return {'agentPos': np.concatenate([zeros, f32[:, :5]]),
-                'inventory': np.concatenate([inv0[None], raw[:, 32:38].astype(np.float32)]),
+                'inventory': np.concatenate([inv0[None], inv.astype(np.float32)]),
                 'compass': np.concatenate([np.zeros((1, 1), np.float32), f32[:, 6:7]]),
-                'grid': grids, 'reward': f32[:, 5].astype(np.float64), 'done': raw[:, 38].astype(bool),
+                'grid': grids, 'reward': f32[:, 5].astype(np.float64), 'done': raw[:, 42].astype(bool),
                 'actions': actions, 'task': int(task)}
 
     def collect(self, dump=True):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IGW_VERSION 3
+#define IGW_VERSION 4
 /* igw_config.lanes_per_env == 0 picks the group width measured fastest on an MI355X for the batch size
  * (profiles/r02_sweep_lanes*.txt): 32 lanes per env up to IGW_AUTO_32_MAX envs, 16 up to IGW_AUTO_16_MAX, 8 up to
  * IGW_AUTO_8_MAX, 4 beyond (a launch then has between about 512 and 4,096 wavefronts for 1,024 SIMDs).  64 (one
@@ -68,8 +68,10 @@ extern "C" {
  * written by igw_prepare_tasks and by the on-device RandomTasks generator */
 #define IGW_LEVEL_INDEX_BYTES 160
 #define IGW_TASK_INDEX_BYTES (IGW_GRID_Y * IGW_LEVEL_INDEX_BYTES)
-/* bytes of per-env agent state and of per-task metadata (layouts below) */
+/* bytes of per-env agent state (two records) , of the per-step output record and of per-task metadata (layouts below) */
 #define IGW_AGENT_BYTES 64
+#define IGW_AUX_BYTES 16
+#define IGW_OUT_BYTES 64
 #define IGW_TASK_META_BYTES 128
 /* striped device counters: [IGW_STAT_STRIPES][8] uint64, stripe = 64 B */
 #define IGW_STAT_STRIPES 64
@@ -83,8 +85,9 @@ extern "C" {
                                * movement / camera values, camera deltas beyond +-IGW_CAMERA_MAX, inventory /
                                * hotbar ids outside 0..6 (the reference raises ValueError there,
                                * core/world.py:354-355) */
-#define IGW_STAT_BAD_TASK 6   /* task rows with a block id outside 0..7 in target or starting grid (the ids of
-                               * env.py:85); the step kernels never count such a cell as a match */
+#define IGW_STAT_BAD_TASK 6   /* task rows with a block id outside 0..7 in target, starting grid or full grid (the
+                               * ids of env.py:85): such a cell is read as empty (0), so the row stays consistent
+                               * (target size, bounding boxes, colour index) */
 /* largest |camera delta| per step (degrees; same bound as init_pose's yaw / pitch): the reference wraps yaw by
  * repeated subtraction of 360 (core/world.py:451-456), which never ends for a finite but huge value */
 #define IGW_CAMERA_MAX 1e6
@@ -122,23 +125,39 @@ typedef struct igw_config {
 } igw_config;
 
 /*
- * Agent state, IGW_AGENT_BYTES per env (Agent, core/world.py:8-29, + the ints
- * GridWorld / Task / SizeReward keep per episode):
+ * Agent state, IGW_AGENT_BYTES per env (Agent, core/world.py:8-29, + GridWorld.step_no): rewritten whole by every
+ * step, one 16-byte piece per lane of the env's quad:
  *   0  f64 x, y, z        agent.position
  *   24 f64 yaw            agent.rotation[0]
  *   32 f64 pitch          agent.rotation[1]
  *   40 f64 vy             agent.dy            (leaks through reset)
- *   48 u16 step_no        GridWorld.step_no   (saturates at 65535)
- *   50 i16 size           SizeReward.size
- *   52 u16 prev_size      _synthetic_task.prev_grid_size (bits 0-14); bit 15: histogram changed while the
- *                         reference kept its cached max_int (a change with wrong_placement == 0)
- *   54 i16 max_int        _synthetic_task.max_int
- *   56 i8  inventory[6]   agent.inventory
- *   62 u16 pack           bits 0-1 agent.time_int_steps code (0,1,2,3 = 2,4,8,12), bits 2-4
- *                         agent.active_block (both leak through reset), bits 5-15 target_size of the
- *                         synthetic task (copied from the task table by reset, so a step needs no
- *                         task-table access unless the grid changed)
+ *   48 i16 inventory[6]   agent.inventory: 20 - (blocks of that colour in the world), i.e. -1069..20 -- the
+ *                         reference's Python ints are unbounded (env.py:243-246: one decrement per starting block)
+ *   60 u16 step_no        GridWorld.step_no   (saturates at 65535)
+ *   62 u16 pack           bits 0-1 agent.time_int_steps code (0,1,2,3 = 2,4,8,12), bits 2-4 agent.active_block
+ *                         (both leak through reset)
  * A fresh agent (Agent.__init__) is inventory 20 x 6, pack = 1 << 2 (time_int_steps 2, BLUE).
+ *
+ * Episode state, IGW_AUX_BYTES per env (the ints GridWorld / Task / SizeReward keep per episode + the env's task):
+ * read by every step, written only by the steps that change it (a block placed or broken, SizeReward's first
+ * step, a reset):
+ *   0  i16 size           SizeReward.size
+ *   2  u16 prev_size      _synthetic_task.prev_grid_size (bits 0-14); bit 15: histogram changed while the
+ *                         reference kept its cached max_int (a change with wrong_placement == 0)
+ *   4  i16 max_int        _synthetic_task.max_int
+ *   6  i16 target_size    _synthetic_task.target_size (copied from the task table by reset, so a step needs no
+ *                         task-table access unless the grid changed)
+ *   8  i32 task           the env's row of the task table (GridWorld._task)
+ *   12 u32 episode        episodes started (every reset adds 1): keys the on-device task samplers and the
+ *                         trajectory log
+ *
+ * Per-step outputs, IGW_OUT_BYTES per env (env.py:281-303), written whole by every step:
+ *   0  f32 agentPos[5]    x, y, z, pitch, yaw
+ *   20 f32 inventory[6]
+ *   44 f32 compass        yaw - 180
+ *   48 f32 reward         (float) of the double reward
+ *   52 u8  done
+ *   53 ..  zero
  *
  * Task metadata, IGW_TASK_META_BYTES per task (written by igw_prepare_tasks):
  *   0  f64 init_pose[5]   x, y, z, yaw, pitch (GridWorld.initial_position/rotation)
@@ -146,8 +165,8 @@ typedef struct igw_config {
  *   42 i16 env_max_int    GridWorld.max_int at reset (user task on the starting grid)
  *   44 u8  has_start      starting grid not empty
  *   48 i8  bbox[4][4]     per rotation xmin, xmax, zmin, zmax of the synthetic target
- *   64 i8  inv_init[6]    inventory at reset (20 - blocks of that colour in the start grid)
- *   70 ..  zero
+ *   64 i16 inv_init[6]    inventory at reset (20 - blocks of that colour in the start grid)
+ *   76 ..  zero
  */
 typedef struct igw_buffers {
     /* state */
@@ -155,22 +174,16 @@ typedef struct igw_buffers {
     uint32_t* occ;         /* [N][IGW_OCC_WORDS]     occupancy bitmap of grid */
     uint16_t* hist;        /* [N][IGW_HIST_ROW]      vote histogram of (grid - start) against the synthetic target */
     void* agent;           /* [N][IGW_AGENT_BYTES] */
-    int32_t* env_task;     /* [N] index into the task table */
+    void* aux;             /* [N][IGW_AUX_BYTES] */
     /* task table */
     int8_t* task_target;   /* [T][IGW_GRID_STRIDE] synthetic target = target - start (env.py:230) */
     int8_t* task_start;    /* [T][IGW_GRID_STRIDE] dense starting grid (env.py:226) */
     uint32_t* task_start_occ; /* [T][IGW_OCC_WORDS] its occupancy bitmap */
     void* task_meta;       /* [T][IGW_TASK_META_BYTES] */
-    /* per-step outputs (env.py:281-303) */
-    float* agent_pos;      /* [N][5] x, y, z, pitch, yaw */
-    float* inventory;      /* [N][6] */
-    float* compass;        /* [N]    yaw - 180 */
-    float* reward;         /* [N]    (float) of the double reward */
-    uint8_t* done;         /* [N] */
-    uint64_t* stats;       /* [IGW_STAT_STRIPES][8], caller zeroes; may be NULL */
-    uint32_t* episode;     /* [N] episodes started per env (every reset adds 1); keys the on-device task samplers and
-                            * the trajectory log; may be NULL unless one of those is enabled */
     uint8_t* task_index;   /* [T][IGW_TASK_INDEX_BYTES] colour index of task_target (task table, 16-byte aligned) */
+    /* per-step outputs (env.py:281-303): agentPos, inventory, compass, reward, done of every env in one record */
+    void* out;             /* [N][IGW_OUT_BYTES] */
+    uint64_t* stats;       /* [IGW_STAT_STRIPES][8], caller zeroes; may be NULL */
 } igw_buffers;
 
 typedef struct igw_ctx igw_ctx;
@@ -195,14 +208,14 @@ int igw_prepare_tasks(igw_ctx* ctx, int32_t first, int32_t n, const int8_t* user
                       const double* init_pose, void* stream);
 
 /* Task generator on the device (CustomTasks.reset, gridworld/tasks/task_set.py:53-56): when enabled every
- * reset -- igw_reset and the auto-reset inside the step kernels -- first draws env_task uniformly from rows
+ * reset -- igw_reset and the auto-reset inside the step kernels -- first draws the env's task (aux record) uniformly from rows
  * [0, n_tasks) of the task table (n_tasks <= 0: the whole table) with a counter RNG keyed by (seed,
- * env_index_base + env, episode[env]).  Same distribution as the reference's np.random.choice, not the
- * same stream; replayable from a HIP graph (the key lives in device memory).  Needs igw_buffers.episode. */
+ * env_index_base + env, the env's episode counter).  Same distribution as the reference's np.random.choice, not the
+ * same stream; replayable from a HIP graph (the key lives in device memory: the aux record's episode counter). */
 int igw_set_task_sampling(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t n_tasks);
 
 /* RandomTasks.sample_task on the device (gridworld/tasks/task_set.py:135-157): when enabled every reset first
- * writes a freshly sampled target into the env's OWN task row (env_task[env] := env; needs num_tasks >=
+ * writes a freshly sampled target into the env's OWN task row (its task := env; needs num_tasks >=
  * num_envs; starting grid empty, the row's init pose is kept): per height level one block uniform over the
  * 11 x 11 plane, then max_blocks - 1 further blocks on distinct cells within Chebyshev distance max_dist of
  * it (all of them when fewer are free -- where the reference's rejection loop never ends), colours uniform in
@@ -214,16 +227,16 @@ int igw_set_random_tasks(igw_ctx* ctx, int32_t enabled, uint64_t seed, int32_t m
 
 /* Episode log on the device (what the reference's Logged wrapper collects per step, gridworld/wrappers.py:
  * 89-121, minus video): for envs [0, n_logged) every step writes one IGW_TRAJ_BYTES record at
- *   records[env][episode[env] & 1][step_no - 1]     (two episodes of `capacity` steps per env, so a finished
+ *   records[env][episode & 1][step_no - 1]          (two episodes of `capacity` steps per env, so a finished
  * episode stays readable while the next one is written; steps beyond capacity are not recorded) and keeps
- *   heads[env][episode[env] & 1] = { task row, steps recorded, episode number, finished }  (int32 x 4) current;
+ *   heads[env][episode & 1] = { task row, steps recorded, episode number, finished }  (int32 x 4) current;
  * `finished` is the done flag of the last recorded step (1: the episode in this slot is complete).
  * Record layout (little endian):
- *    0 f32 agentPos[5]   20 f32 reward   24 f32 compass   28 i32 change: -1, or cell | (colour & 0xff) << 16
- *   32 u8 inventory[6]   38 u8 done      39 u8 action space (igw_action_space)
- *   40 walking: i32 action | flying: f32 movement[3], f32 camera[2] | walking Dict: u8 buttons[8], f32 camera[2]
- *   60 flying: i8 inventory, i8 placement     62 u16 0
- * records / heads NULL disables.  Needs igw_buffers.episode. */
+ *    0 f32 agentPos[5]   20 f32 reward   24 f32 compass   28 i16 inventory[6]
+ *   40 u16 change: 0xffff, or cell (bits 0-10) | colour (bits 11-13)     42 u8 done
+ *   43 u8 action space (igw_action_space, bits 0-1) | flying: inventory (bits 2-4), placement (bits 5-6), as executed
+ *   44 walking: i32 action | flying: f32 movement[3], f32 camera[2] | walking Dict: u8 buttons[8], f32 camera[2]
+ * records / heads NULL disables. */
 #define IGW_TRAJ_BYTES 64
 int igw_set_trajectory_log(igw_ctx* ctx, void* records, int32_t* heads, int32_t n_logged, int32_t capacity);
 

@@ -15,9 +15,17 @@ from gridworld_amd import VecGridWorld  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
-def targets(rng, n, with_start):
+def targets(rng, n, with_start, dense=False):
     tg = np.zeros((n, 9, 11, 11), np.int8)
     st = np.zeros_like(tg)
+    if dense:   # whole floors of one colour in the starting grid: inventories far below zero (env.py:243-246)
+        for e in range(n):
+            if rng.rand() < 0.5:
+                for y in range(rng.randint(1, 5)):
+                    st[e, y] = rng.randint(1, 7)
+                tg[e] = st[e]
+                tg[e].reshape(-1)[rng.randint(0, 1089, 8)] = rng.randint(0, 7, 8)
+        return tg, st
     for e in range(n):
         k = rng.randint(1, 40)
         lv = rng.randint(1, 4)
@@ -68,18 +76,22 @@ def main():
         autoreset = bool(rng.rand() < 0.6)
         with_start = rng.rand() < 0.5
         T = int(rng.choice([30, 90]))
-        tg, st = targets(rng, n, with_start)
+        dense = rng.rand() < 0.12
+        tg, st = targets(rng, n, with_start, dense)
         fg = full_grids(rng, tg) if rng.rand() < 0.4 else None
         # a third of the cases: arbitrary initial poses -- off the 5-degree lattice (general trig path, oracle in
         # device-trig mode), up to the edge of the validated range (clamped occupancy keys, agents outside the zone)
         poses = None
-        if rng.rand() < 0.33:
+        if dense:   # on top of the floors
+            poses = np.zeros((n, 5))
+            poses[:, 1] = np.where(st[:, :, 5, 5].any(1), (st[:, :, 5, 5] != 0).sum(1) - 2 + 0.5 + 1.25, 0.0)
+        elif rng.rand() < 0.33:
             poses = np.stack([rng.uniform(-9.5, 9.5, n), np.where(rng.rand(n) < 0.8, rng.uniform(-0.25, 9.0, n), rng.uniform(-6.0, 30.0, n)),
                               rng.uniform(-9.5, 9.5, n), rng.uniform(-400.0, 400.0, n), rng.uniform(-90.0, 90.0, n)], axis=1)
             if rng.rand() < 0.5:   # half of them on the lattice, at the border
                 poses[:, 3:] = np.round(poses[:, 3:] / 5.0) * 5.0
                 poses[:, [0, 2]] = np.round(poses[:, [0, 2]] * 4.0) / 4.0
-        desc = f'case {c}: n={n} gs={gs} {mode} autoreset={autoreset} start={with_start} full_grid={fg is not None} poses={poses is not None} {kw}'
+        desc = f'case {c}: n={n} gs={gs} {mode} autoreset={autoreset} start={with_start} dense={dense} full_grid={fg is not None} poses={poses is not None} {kw}'
         env = VecGridWorld(n, action_space=mode, autoreset=autoreset, lanes_per_env=gs, **kw)
         env.set_tasks(tg, st, full_grids=fg, init_pose=poses)
         env.reset()

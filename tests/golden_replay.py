@@ -20,7 +20,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 WALK_FIXTURES = ['s1_walk_dummy', 's1_walk_dummy_sizereward', 's2_walk_cdm', 's2_walk_cdm_sizereward',
                  's3_walk_rt20', 's5_scripted', 's5_scripted_scales', 's5_scripted_leak', 's5_init_pose',
-                 's9_walk_no_select_and_place']
+                 's9_walk_no_select_and_place',
+                 # starting grids with hundreds of blocks of one colour: inventories down to -1069 (env.py:243-246)
+                 's12_wide_inventory', 's12_wide_inventory_sizereward']
 FLY_FIXTURES = ['s4_fly_rt20', 's4_fly_cdm', 's9_fly_no_select_and_place']
 DICT_FIXTURES = ['s8_walk_dict']
 # recorded with the reference's sin/cos/atan2 replaced by correctly rounded ones (ref_harness.cr_libm)

@@ -23,14 +23,15 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f'{name} declared in include/igw.h but not exported'
     assert sorted(_lib.EXPORTS) == declared
-    assert L.igw_version() == _lib.VERSION == 3
+    assert L.igw_version() == _lib.VERSION == 4
 
 
 def test_layout_constants_match_header():
     from gridworld_amd import _lib
     src = open(os.path.join(ROOT, 'include', 'igw.h')).read()
     for name, val in (('IGW_GRID_STRIDE', _lib.GRID_STRIDE), ('IGW_CELLS', _lib.CELLS),
-                      ('IGW_AGENT_BYTES', _lib.AGENT_BYTES), ('IGW_TASK_META_BYTES', _lib.TASK_META_BYTES),
+                      ('IGW_AGENT_BYTES', _lib.AGENT_BYTES), ('IGW_AUX_BYTES', _lib.AUX_BYTES), ('IGW_OUT_BYTES', _lib.OUT_BYTES),
+                      ('IGW_TASK_META_BYTES', _lib.TASK_META_BYTES),
                       ('IGW_STAT_STRIPES', _lib.STAT_STRIPES), ('IGW_OCC_WORDS', _lib.OCC_WORDS),
                       ('IGW_TRAJ_BYTES', _lib.TRAJ_BYTES), ('IGW_VERSION', _lib.VERSION),
                       ('IGW_STAT_BAD_POSE', _lib.STAT_BAD_POSE), ('IGW_STAT_BAD_ACTION', _lib.STAT_BAD_ACTION),
@@ -38,7 +39,7 @@ def test_layout_constants_match_header():
         m = re.search(r'#define\s+%s\s+(\d+)' % name, src)
         assert m and int(m.group(1)) == val, name
     assert ctypes.sizeof(_lib.Config) == 64
-    assert ctypes.sizeof(_lib.Buffers) == 17 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.Buffers) == 12 * ctypes.sizeof(ctypes.c_void_p)
     assert _lib.TASK_INDEX_BYTES == 9 * _lib.LEVEL_INDEX_BYTES
 
 

@@ -1,4 +1,4 @@
-"""Multi-process path on CPU (gloo, world size 2): env sharding, barrier, step-count reduction.
+"""Multi-process path on CPU (gloo, world sizes 2 and 8): env sharding, barrier, step-count reduction.
 The data path has no collective (envs are independent); this covers what bench.py does around it."""
 import os
 import socket
@@ -41,9 +41,11 @@ WORKER = textwrap.dedent('''
     via = gd.gather_counts_rccl(steps, None)   # no GPU here: the documented gloo path
     assert via == (counts, 'gloo'), via
     assert gd.reduce_windows([0.1 * (rank + 1), 0.3 - 0.1 * rank]) == [0.2, 0.3]
+    assert gd.gather_floats(1.5 + rank) == [1.5, 2.5]
     if rank == 0:
         print(json.dumps(dict(total=tot, max_elapsed=mx, counts=counts, lo=lo, hi=hi, expect=total * 10, nb_us=nb_us,
-                              released_after_late_rank=stamps[0] >= stamps[1])))
+                              released_after_late_rank=stamps[0] >= stamps[1])), flush=True)
+    gd.shutdown()
 ''') % ROOT
 
 
@@ -101,3 +103,30 @@ def test_bench_self_launches_n_ranks():
     assert d['n_gpus'] == 2 and d['ranks'] == [0, 1]
     assert d['total_steps'] == 2 * 65536 * 20 and d['steps'] == 20 and d['warmup'] == 5
     assert d['windows_max'] == [2e-3, 4e-3]   # per window the max over the two ranks
+
+
+def test_bench_dry_run_eight_ranks_on_four_cpus():
+    """The 8-rank shape of the driver's scaling run, without GPUs and on FEWER CPUs than ranks (taskset to 4): 8 ranks
+    rendezvous, pass the shared-memory barrier of the timing bracket 50 times (its spin backs off to sched_yield, so
+    ranks that share a CPU cannot starve each other), reduce the per-window maxima, gather per-rank values, tear the
+    group down together, and the launcher relays exactly one JSON line with exit code 0."""
+    import json
+    import shutil
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'OMP_NUM_THREADS'):
+        env.pop(k, None)
+    cpus = sorted(os.sched_getaffinity(0))[:4]
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '20', '--warmup', '5', '--dry-run']
+    if shutil.which('taskset'):
+        cmd = ['taskset', '-c', ','.join(map(str, cpus))] + cmd
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['ranks'] == list(range(8)) == d['config']['ranks_seen']
+    assert d['total_steps'] == 8 * 65536 * 20
+    assert d['windows_max'] == [8e-3, 16e-3]
+    assert d['config']['kernel_us_per_rank'] == [10.0 + r for r in range(8)]
+    # the launcher sizes the ranks' thread pools from what the process may really use (affinity / cgroup quota)
+    assert 1 <= d['config']['torch_threads'] <= max(1, d['config']['usable_cpus'])

@@ -14,7 +14,9 @@ def _sparse(dense):
 
 
 @pytest.mark.parametrize('name,envs', [('s5_scripted', range(9)), ('s2_walk_cdm', [0, 7]),
-                                       ('s1_walk_dummy_sizereward', [1]), ('s4_fly_rt20', [0])])
+                                       ('s1_walk_dummy_sizereward', [1]), ('s4_fly_rt20', [0]),
+                                       # inventories of -222, -1069 and -129 at reset (env.py:243-246)
+                                       ('s12_wide_inventory', [0, 2, 6]), ('s12_wide_inventory_sizereward', [1])])
 def test_facade_matches_reference(name, envs):
     import gridworld_amd as G
     fx = GR.load_fixture(name)
@@ -23,6 +25,11 @@ def test_facade_matches_reference(name, envs):
         task = G.Task('chat', fx['targets'][e].astype(np.int32), starting_grid=_sparse(fx['starts'][e]),
                       **fx['task_kwargs'])
         env.set_task(task)
+        if 'init_pose' in fx:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                env.initialize_world(_sparse(fx['starts'][e]), [float(v) for v in fx['init_pose'][e]])
         obs = env.reset()
         assert set(obs) == {'inventory', 'compass', 'dialog', 'grid', 'agentPos'}
         assert obs['grid'].dtype == np.int32 and obs['grid'].shape == (9, 11, 11)

@@ -22,7 +22,7 @@ def test_walking_fixture(name):
 
 
 @pytest.mark.parametrize('gs', [64, 32, 16, 8, 4, 2, 1])
-@pytest.mark.parametrize('name', ['s2_walk_cdm', 's3_walk_rt20', 's5_scripted', 's5_init_pose'])
+@pytest.mark.parametrize('name', ['s2_walk_cdm', 's3_walk_rt20', 's5_scripted', 's5_init_pose', 's12_wide_inventory'])
 def test_walking_fixture_lane_groups(name, gs):
     fx = GR.load_fixture(name)
     GR.replay(fx, _hip(fx, lanes_per_env=gs), max_steps=260)

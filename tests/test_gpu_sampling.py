@@ -98,8 +98,14 @@ def test_state_dict_roundtrip():
         env2.step_walking_ptr(acts[t])
     torch.cuda.synchronize()
     for k, v in final.items():
-        if k != 'stats_buf':
+        if k not in ('stats_buf', 'abi_version'):
             assert torch.equal(v, getattr(env2, k)), k
+    # a snapshot that is not complete (e.g. one of an older ABI, without the colour index) must not load
+    partial = {k: v for k, v in snap.items() if k != 'task_index'}
+    with pytest.raises(ValueError):
+        env2.load_state_dict(partial)
+    with pytest.raises(ValueError):
+        env2.load_state_dict({**snap, 'abi_version': 3})
 
 
 def test_sub_batches_on_streams_equal_whole_batch():

@@ -172,6 +172,9 @@ def test_input_validation_and_counters():
     L.check(wd.lib.igw_prepare_tasks(wd.ctx, 0, n, rows9.data_ptr(), None, None, None, None, wd._stream()), 'prep')
     torch.cuda.synchronize()
     assert wd.stats()['bad_tasks'] == 1
+    # ... and the row stays consistent: the cell is read as empty (target size, colour index)
+    clean = odd[3].clone(); clean[0, 5, 5] = 0
+    assert int(wd.task_meta[3, 40:42].cpu().numpy().view(np.int16)[0]) == int((clean != 0).sum())
     # the fused loops do not write the episode log: refused while it is enabled (C ABI: IGW_ERR_INVALID)
     w = VecGridWorld(n, autoreset=True)
     w.set_tasks(tg)

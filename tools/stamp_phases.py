@@ -30,8 +30,7 @@ env.reset()
 g = torch.Generator(device=env.device)
 g.manual_seed(1)
 sn = torch.randint(0, 250, (N,), generator=g, device=env.device, dtype=torch.int32)
-env.agent_buf[:, 48] = (sn & 0xff).to(torch.uint8)
-env.agent_buf[:, 49] = (sn >> 8).to(torch.uint8)
+env.set_step_no(sn)
 if FLY:
     import ctypes
     mvt = torch.empty((60, N, 3), device=env.device).uniform_(-1, 1, generator=g)
