@@ -356,7 +356,15 @@ typedef double vd2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long vu2 __attribute__((ext_vector_type(2)));
 typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
 // Per-step outputs are written once and next read by another launch: non-temporal stores (-1 % launch time).
-template <class T> __device__ inline void st(T* p, T v) { __builtin_nontemporal_store(v, p); }
+// (through a pointer in the GLOBAL address space: pointers that went through the kernarg re-read or an inline-asm
+// barrier are generic to the compiler, and a flat store also counts on lgkmcnt and may alias LDS for its wait insertion)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IGW_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(uintptr_t)(p))
+#else
+#define IGW_GLOBAL(T, p) (p)
+#endif
+template <class T> __device__ inline void st(T* p, T v) { __builtin_nontemporal_store(v, IGW_GLOBAL(T, p)); }
+template <class T> __device__ inline void gstore(T* p, T v) { *IGW_GLOBAL(T, p) = v; }   // plain store, global address space
 __device__ inline void st4(void* p, const uint4& v) { st(reinterpret_cast<vu4*>(p), vu4{v.x, v.y, v.z, v.w}); }
 __device__ inline void env_store_pose(const Env& e, AgentRec* rec) {
     vd2* d = reinterpret_cast<vd2*>(rec);

@@ -63,8 +63,20 @@ __device__ inline void stamp(const KParams&, int) {}
 __device__ inline void stamp_features(const KParams&, unsigned long long) {}
 #endif
 
+// Counter atomics go out as GLOBAL atomics without return.  Through a generic pointer the compiler emits flat_atomic and,
+// because a flat access may alias LDS, puts an s_waitcnt vmcnt(0) in front of it whenever global stores are in flight:
+// at the end of a step that waited for the acknowledgement of every store of the wavefront (histogram rows, records) --
+// 700 cycles on every wavefront with something to count.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) unsigned long long global_u64;
+__device__ inline void counter_add(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_fetch_add((global_u64*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+__device__ inline void counter_add(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+#endif
 __device__ inline void stat_add(unsigned long long* stats, int which, unsigned long long v) {
-    if (stats) atomicAdd(&stats[(blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + which], v);
+    if (stats) counter_add(&stats[(blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + which], v);
 }
 
 struct BBox {
@@ -1029,6 +1041,7 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
                                  [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok, const TailParams& tp, int size_in) {
     const StepOut o = finish_step(tp, e, env_max_int, size_new, mi);
     const bool do_reset = active && o.done && tp.autoreset;
+    const uint4 ob = out_piece_step(e, G.gl & 3);   // obs of this step (env.py:281-289), before a reset changes the registers
     uint32_t ep = e.episode;
     const int task_old = task;
     int generated_size = -1;
@@ -1057,26 +1070,23 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
     const bool aux_dirty = changed || do_reset || e.size != size_in;
     if (do_reset) reset_env_regs(e, rm, false, generated_size);
     if (G.gl == 0 && ch.idx >= 0 && !do_reset) {
-        grid_g[ch.idx] = (int8_t)ch.new_val;
-        tp.occ[(size_t)env * OCC_WORDS + (ch.bit >> 5)] = ch.occ_word;
+        gstore(grid_g + ch.idx, (int8_t)ch.new_val);
+        gstore(tp.occ + (size_t)env * OCC_WORDS + (ch.bit >> 5), ch.occ_word);
     }
     if constexpr (GS >= 4) {
-        // the reset's record and observations go the way the step's went (same lane -> same address: program order)
-        if (do_reset && G.gl < 4) {
-            st4(reinterpret_cast<uint4*>(tp.agent + env) + G.gl, agent_piece(G.gl, e.x, e.y, e.z, e.yaw, e.pitch, e.vy, env_pack_piece3(e)));
-            if (G.gl < 3 && !IGW_DIAG_FLAG(p, 16)) st4(reinterpret_cast<uint4*>(tp.out + env) + G.gl, out_piece_reset(e, G.gl));
+        if (G.gl < 4) {
+            // a reset's agent record goes the way the step's went (same lane -> same address: program order)
+            if (do_reset) st4(reinterpret_cast<uint4*>(tp.agent + env) + G.gl, agent_piece(G.gl, e.x, e.y, e.z, e.yaw, e.pitch, e.vy, env_pack_piece3(e)));
+            // the whole output record in ONE store instruction: observations (of the reset, if one happened) by lanes
+            // 0..2, reward + done by lane 3
+            if (!IGW_DIAG_FLAG(p, 16))
+                st4(reinterpret_cast<uint4*>(tp.out + env) + G.gl,
+                    G.gl == 3 ? out_piece_result((float)o.reward, o.done) : do_reset ? out_piece_reset(e, G.gl) : ob);
         }
-        // reward + done (lane 3) and -- when it changed -- the aux record (lane 0): two arrays, ONE store instruction
-        const bool is_res = G.gl == 3;
-        const uint4 v = is_res ? out_piece_result((float)o.reward, o.done) : env_pack_aux(e, task);
-        void* dst = is_res ? (void*)(reinterpret_cast<uint4*>(tp.out + env) + 3) : (void*)(tp.aux + env);
-        if ((is_res && !IGW_DIAG_FLAG(p, 16)) || (G.gl == 0 && aux_dirty)) st4(dst, v);
+        if (G.gl == 0 && aux_dirty) st4(tp.aux + env, env_pack_aux(e, task));
     } else if (G.gl == 0) {
         if (do_reset) env_store(e, tp.agent + env);
-        if (!IGW_DIAG_FLAG(p, 16)) {
-            if (do_reset) out_store(tp.out + env, e, true, (float)o.reward, o.done);
-            else st4(reinterpret_cast<uint4*>(tp.out + env) + 3, out_piece_result((float)o.reward, o.done));
-        }
+        if (!IGW_DIAG_FLAG(p, 16)) out_store(tp.out + env, e, do_reset, (float)o.reward, o.done);
         if (aux_dirty) aux_store(e, task, tp.aux + env);
     }
     {   // the wave's counters: one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
@@ -1084,9 +1094,9 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
                        m_reset = __ballot(do_reset && G.gl == 0);
         if ((m_need | m_cell | m_reset) != 0 && tp.stats != nullptr && G.lane == 0) {
             unsigned long long* st = tp.stats + (blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8;
-            if (m_need) atomicAdd(st + IGW_STAT_CHANGED, (unsigned long long)__builtin_popcountll(m_need));
-            if (m_cell) atomicAdd(st + IGW_STAT_RESCANS, (unsigned long long)__builtin_popcountll(m_cell));
-            if (m_reset) atomicAdd(st + IGW_STAT_RESETS, (unsigned long long)__builtin_popcountll(m_reset));
+            if (m_need) counter_add(st + IGW_STAT_CHANGED, (unsigned long long)__builtin_popcountll(m_need));
+            if (m_cell) counter_add(st + IGW_STAT_RESCANS, (unsigned long long)__builtin_popcountll(m_cell));
+            if (m_reset) counter_add(st + IGW_STAT_RESETS, (unsigned long long)__builtin_popcountll(m_reset));
         }
     }
     stamp(p, 6);
@@ -1270,21 +1280,16 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // ... and counts as consumed HERE: the counter is in order over loads and stores, so a first use at the end of
     // the step would wait for every store issued from now on (observations, histogram pieces) as well
     asm volatile("" : "+v"(start_val), "+v"(env_max_int));
-    // Pose and observations are final: their stores are issued here -- behind that wait, so it does not wait for
-    // them -- and complete in the shadow of the histogram update's LDS round trips, not at the very end of the
-    // wave (issued from tail_step instead: +0.7 % launch time, same-box A/B).  (A reset at the end of this step
-    // overwrites them: same lane, same addresses, program order.)
+    // The agent record is final (pose, inventory, step_no): its store is issued here -- behind that wait, so it does
+    // not wait for it -- and completes in the shadow of the histogram update's LDS round trips, not at the very end of
+    // the wave.  (A reset at the end of this step overwrites it: same lanes, same addresses, program order.)  The
+    // output record goes out whole at the end of the step, with reward and done: written in two parts (observations
+    // here, results there) the 64-byte records reached memory as partial lines and the launch took 2 % longer.
     if constexpr (GS >= 4) {
-        if (active && G.gl < 4) {   // the whole agent record in ONE store instruction, the observations in a second
+        if (active && G.gl < 4)   // the whole agent record in ONE store instruction: lane q of the quad stores piece q
             st4(reinterpret_cast<uint4*>(p.agent + env) + G.gl, agent_piece(G.gl, e.x, e.y, e.z, e.yaw, e.pitch, e.vy, env_pack_piece3(e)));
-            if (G.gl < 3 && !IGW_DIAG_FLAG(p, 16)) st4(reinterpret_cast<uint4*>(p.out + env) + G.gl, out_piece_step(e, G.gl));
-        }
     } else if (writer) {
         env_store(e, p.agent + env);
-        if (!IGW_DIAG_FLAG(p, 16)) {
-#pragma unroll
-            for (int q = 0; q < 3; q++) st4(reinterpret_cast<uint4*>(p.out + env) + q, out_piece_step(e, q));
-        }
     }
     stamp(p, 4);
     const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch, start_val);
