@@ -365,6 +365,7 @@ typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
 #endif
 template <class T> __device__ inline void st(T* p, T v) { __builtin_nontemporal_store(v, IGW_GLOBAL(T, p)); }
 template <class T> __device__ inline void gstore(T* p, T v) { *IGW_GLOBAL(T, p) = v; }   // plain store, global address space
+template <class T> __device__ inline T gload(const T* p) { return *IGW_GLOBAL(const T, p); }  // plain load, global address space
 __device__ inline void st4(void* p, const uint4& v) { st(reinterpret_cast<vu4*>(p), vu4{v.x, v.y, v.z, v.w}); }
 __device__ inline void env_store_pose(const Env& e, AgentRec* rec) {
     vd2* d = reinterpret_cast<vd2*>(rec);

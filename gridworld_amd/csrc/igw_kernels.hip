@@ -125,26 +125,34 @@ __device__ inline void rot_bboxes(const BBox& b, bool empty, int* out4) {
 // step that one of its episodes runs out in it (step_no + 1 == max_steps, the usual end of an episode) fetches
 // these with the step's other inputs instead of at the end, where two dependent memory round trips -- each behind an
 // s_waitcnt that also waits for the step's stores -- used to make the resetting wavefront the last of its CU.
-struct ResetMeta {
+struct ResetVals {
     double pose[5];
     int target_size;
     uint32_t inv01, inv23, inv45;  // env.py:243-246: 20 - blocks of the colour in the starting grid
     bool has_start;
 };
+struct ResetMeta {   // bytes 0..47 and 64..79 of the metadata row, RAW: nothing is converted where it is loaded,
+    uint4 a, b, c, d;  // so nothing waits for these loads before reset_decode() -- the row's layout is in include/igw.h
+};
 __device__ inline ResetMeta load_reset_meta(const TaskMeta* meta) {
-    ResetMeta r;
-#pragma unroll
-    for (int i = 0; i < 5; i++) r.pose[i] = meta->pose[i];
-    r.target_size = meta->target_size;
-    r.has_start = meta->has_start != 0;
-    const uint4 iv = *reinterpret_cast<const uint4*>(meta->inv_init);  // (one aligned dwordx4; the fourth word is padding)
-    r.inv01 = iv.x; r.inv23 = iv.y; r.inv45 = iv.z;
-    return r;
+    const uint4* m = reinterpret_cast<const uint4*>(meta);
+    return ResetMeta{gload(m), gload(m + 1), gload(m + 2), gload(m + 4)};
+}
+__device__ inline double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+__device__ inline ResetVals reset_decode(const ResetMeta& r) {
+    ResetVals v;
+    v.pose[0] = u2d(r.a.x, r.a.y); v.pose[1] = u2d(r.a.z, r.a.w);
+    v.pose[2] = u2d(r.b.x, r.b.y); v.pose[3] = u2d(r.b.z, r.b.w);
+    v.pose[4] = u2d(r.c.x, r.c.y);
+    v.target_size = (int)(int16_t)(r.c.z & 0xffffu);
+    v.has_start = (r.c.w & 0xffu) != 0;
+    v.inv01 = r.d.x; v.inv23 = r.d.y; v.inv45 = r.d.z;
+    return v;
 }
 // per-lane part of GridWorld.reset (env.py:206-261): everything except the grid / bitmap rows.
 // generated_size >= 0: the task row was just written by the on-device RandomTasks generator of this wave (its
 // metadata is taken from registers, not re-read: target size as given, empty start => full inventory).
-__device__ inline void reset_env_regs(Env& e, const ResetMeta& m, bool keep_size, int generated_size = -1) {
+__device__ inline void reset_env_regs(Env& e, const ResetVals& m, bool keep_size, int generated_size = -1) {
     if (!keep_size) e.size = 0;  // SizeReward.reset, env.py:321-323
     e.step_no = 0;               // env.py:217
     e.prev_size = 0;             // _synthetic_task.reset(): prev_grid_size = 0, max_int = 0 (task.py:74-86)
@@ -162,7 +170,7 @@ __device__ inline void reset_env_regs(Env& e, const ResetMeta& m, bool keep_size
     // agent.dy, time_int_steps, active_block are NOT reset by the reference
 }
 __device__ inline void reset_env_regs(Env& e, const TaskMeta* meta, bool keep_size, int generated_size = -1) {
-    reset_env_regs(e, load_reset_meta(meta), keep_size, generated_size);
+    reset_env_regs(e, reset_decode(load_reset_meta(meta)), keep_size, generated_size);
 }
 
 // A reset counts a new episode and, with a task generator on the device, picks the env's next task row.
@@ -303,15 +311,28 @@ __device__ inline int sample_random_task_wave(const KParams& p, int env, uint32_
 __device__ inline void reset_rows_wave(const KParams& p, int env, int task, bool has_start, uint32_t* occ_s) {
     const int lane = __lane_id();
     uint4* dg = reinterpret_cast<uint4*>(p.grid + (size_t)env * STRIDE);
+    uint4* dh = reinterpret_cast<uint4*>(p.hist + (size_t)env * HIST_ROW);
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    if (!has_start) {   // (wave-uniform) no starting grid: stores only -- nothing to load, so nothing to wait for
+        for (int c = lane; c < CHUNKS; c += WAVE) gstore(dg + c, zero);
+        if (lane < OCC_WORDS) {
+            gstore(p.occ + (size_t)env * OCC_WORDS + lane, 0u);
+            if (occ_s) occ_s[OCC_VAR0 + lane] = 0u;
+        }
+        gstore(dh + lane, zero);
+        return;
+    }
     const uint4* sg = reinterpret_cast<const uint4*>(p.task_start + (size_t)task * STRIDE);
-    for (int c = lane; c < CHUNKS; c += WAVE) dg[c] = has_start ? sg[c] : make_uint4(0, 0, 0, 0);
+    // (global address space throughout: these pointers came through a scalar-register barrier and are generic to the
+    // compiler, which waits for every memory operation in flight in front of a flat one)
+    for (int c = lane; c < CHUNKS; c += WAVE) gstore(dg + c, has_start ? gload(sg + c) : zero);
     if (lane < OCC_WORDS) {
-        const uint32_t v = has_start ? p.task_start_occ[(size_t)task * OCC_WORDS + lane] : 0u;
-        p.occ[(size_t)env * OCC_WORDS + lane] = v;
+        const uint32_t v = has_start ? gload(p.task_start_occ + (size_t)task * OCC_WORDS + lane) : 0u;
+        gstore(p.occ + (size_t)env * OCC_WORDS + lane, v);
         if (occ_s) occ_s[OCC_VAR0 + lane] = v;
     }
     // grid == start  =>  synthetic grid empty  =>  no votes
-    reinterpret_cast<uint4*>(p.hist + (size_t)env * HIST_ROW)[lane] = make_uint4(0, 0, 0, 0);
+    gstore(dh + lane, zero);
 }
 
 // The agent record as its four 16-byte pieces, lane q of the env's (first) quad stores piece q: ONE store instruction
@@ -338,8 +359,8 @@ struct Motion {  // get_motion_vector (core/world.py:163-201): constant over the
 };
 
 // World.step (core/world.py:434-456) after action parsing, first half: movement, camera, place / break -- in two
-// parts with the ray march (hit_test) between them, because the march of an env need not run on its own lanes
-// (step_kernel shares the marches of a block over its wavefronts).
+// parts with the ray march (hit_test) between them: world_act_pre needs nothing of the occupancy row, hit_test and
+// world_act_post do.
 struct ActPre {
     bool want_sight, add, remove;
     double vx, vy, vz;  // sight vector (get_sight_vector, core/world.py:312-318); only when want_sight
@@ -446,8 +467,17 @@ __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* 
             const int cell = cell_of(h.bx, h.by, h.bz);
             // colour of the block: the one int8 the physics ever needs (L1-bypassing load: a fused
             // rollout may have written this row earlier in the same launch)
+#if defined(__HIP_DEVICE_COMPILE__)
+            // ... as inline assembly: the compiler does not know that a load is pending on ch.old_val, so nothing waits
+            // for it here.  (Written as C++, the masked load's value is needed where this branch ends -- the merge with
+            // the 0 of the lanes that do not break: s_waitcnt vmcnt(0) eleven instructions behind the load, a full
+            // memory round trip in the middle of the step for every wavefront with a break, one in five.)
+            // finish_break waits for it where the colour is needed, behind the physics.
+            asm volatile("global_load_ubyte %0, %1, off sc1" : "+v"(ch.old_val) : "v"(reinterpret_cast<const uint8_t*>(grid_g) + cell) : "memory");
+#else
             ch.old_val = (int)__hip_atomic_load(reinterpret_cast<const uint8_t*>(grid_g) + cell, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
+#endif
             ch.idx = cell;
             ch.bit = occ_bit_hbm(h.bx, h.by, h.bz);
             ch.new_val = 0;
@@ -483,8 +513,11 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
 }
 
 // remove_block's inventory refund (env.py:146-153 via the on_remove callback), once the colour has arrived
-__device__ inline void finish_break(Env& e, const CellChange& ch) {
+__device__ inline void finish_break(Env& e, CellChange& ch) {
     if (ch.idx >= 0 && ch.new_val == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ch.old_val) : : "memory");   // the colour load of world_act_post
+#endif
         const int texture = old_colour(ch);
         if (texture >= 1 && texture <= 6) inv_add(e, texture - 1, 1);
     }
@@ -1032,6 +1065,21 @@ template <int OFFSET = 0>
 __device__ inline const KParams& kernarg_again(const KParams& p) { return p; }
 #endif
 
+// What the in-step reset reads of the kernel parameters (without the generator / episode-log extras), as one batch of
+// scalar loads: every other field of the copy is dead.
+__device__ inline KParams reset_params(const KParams& p) {
+    KParams q = {};
+    q.sample_tasks = p.sample_tasks; q.n_tasks = p.n_tasks; q.rt_enabled = p.rt_enabled;
+    q.sample_seed = p.sample_seed; q.env_base = p.env_base;
+    q.task_meta = p.task_meta; q.grid = p.grid; q.occ = p.occ; q.hist = p.hist;
+    q.task_start = p.task_start; q.task_start_occ = p.task_start_occ;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(q.sample_tasks), "+s"(q.n_tasks), "+s"(q.rt_enabled), "+s"(q.sample_seed), "+s"(q.env_base),
+                 "+s"(q.task_meta), "+s"(q.grid), "+s"(q.occ), "+s"(q.hist), "+s"(q.task_start), "+s"(q.task_start_occ));
+#endif
+    return q;
+}
+
 // The end of a step: reward / done, the in-step reset, the last stores.  size_in: SizeReward.size as the step loaded it
 // (the aux record goes back to memory only when something in it changed).
 template <int GS, int MODE, bool EXTRA>
@@ -1046,14 +1094,25 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
     const int task_old = task;
     int generated_size = -1;
     bool has_start = false;
-    if (do_reset) {
-        ep = next_task(p, env, e, task);  // the next episode's task (task generators on the device)
-        // (an episode that ends early -- target completed -- or a task that was only just chosen: fetched now)
-        if (!pre_ok) rm = load_reset_meta(p.task_meta + task);
-        has_start = !p.rt_enabled && rm.has_start;
+    ResetVals rv = {};
+    if (__any(do_reset)) {   // (one wavefront in sixteen)
+        // The kernel parameters the reset path needs, read from the kernarg segment in ONE batch: read where they are
+        // used, each of eight scalar loads was followed by its own s_waitcnt -- eight scalar-memory round trips one
+        // after the other in the wavefronts that already have the most to do.
+        KParams rq;
+        if constexpr (EXTRA) rq = p;   // (the generator and the episode log use most of them)
+        else rq = reset_params(p);
+        const KParams& rp = rq;
+        if (do_reset) {
+            ep = next_task(rp, env, e, task);  // the next episode's task (task generators on the device)
+            // (an episode that ends early -- target completed -- or a task that was only just chosen: fetched now)
+            if (!pre_ok) rm = load_reset_meta(rp.task_meta + task);
+            rv = reset_decode(rm);
+            has_start = !rp.rt_enabled && rv.has_start;
+        }
+        resolve_resets<GS, EXTRA>(G, rp, do_reset, env, task, has_start, ep, nullptr,
+                                  reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size);
     }
-    resolve_resets<GS, EXTRA>(G, p, do_reset, env, task, has_start, ep, nullptr,
-                              reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size);
     prio_at<true, 7>(boost);
 #ifdef IGW_DIAG
     {
@@ -1068,7 +1127,7 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
         if (p.traj && env < p.traj_n && G.gl == 0) write_trajectory<MODE>(p, a, env, task_old, ep, e, ch, o, do_reset, task);
     }
     const bool aux_dirty = changed || do_reset || e.size != size_in;
-    if (do_reset) reset_env_regs(e, rm, false, generated_size);
+    if (do_reset) reset_env_regs(e, rv, false, generated_size);
     if (G.gl == 0 && ch.idx >= 0 && !do_reset) {
         gstore(grid_g + ch.idx, (int8_t)ch.new_val);
         gstore(tp.occ + (size_t)env * OCC_WORDS + (ch.bit >> 5), ch.occ_word);
@@ -1264,8 +1323,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     if (p.size_reward && e.step_no == 1) env_max_int = p.task_meta[task].env_max_int;
     stamp(p, 2);
     const bool changed = active && ch.idx >= 0 && !IGW_DIAG_FLAG(p, 1);
-    // the histogram row, target level, start byte and bounding boxes of every changed env start moving into
-    // LDS now and land while the physics runs
+    // the histogram row and the colour-index block of the changed level of every changed env start moving into LDS
+    // now (LDS-DMA) and land while the physics runs
     const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env_r, task, ch);
     const TailParams tp = tail_params(kernarg_again<STEP_KERNARG_HEAD>(p));
     prio_at<true, 3>(boost);
@@ -1280,6 +1339,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // ... and counts as consumed HERE: the counter is in order over loads and stores, so a first use at the end of
     // the step would wait for every store issued from now on (observations, histogram pieces) as well
     asm volatile("" : "+v"(start_val), "+v"(env_max_int));
+    // (the prefetched reset metadata too: raw words, decoded in tail_step)
+    asm volatile("" : "+v"(pre.a.x), "+v"(pre.a.y), "+v"(pre.a.z), "+v"(pre.a.w), "+v"(pre.b.x), "+v"(pre.b.y), "+v"(pre.b.z), "+v"(pre.b.w));
+    asm volatile("" : "+v"(pre.c.x), "+v"(pre.c.y), "+v"(pre.c.z), "+v"(pre.c.w), "+v"(pre.d.x), "+v"(pre.d.y), "+v"(pre.d.z));
     // The agent record is final (pose, inventory, step_no): its store is issued here -- behind that wait, so it does
     // not wait for it -- and completes in the shadow of the histogram update's LDS round trips, not at the very end of
     // the wave.  (A reset at the end of this step overwrites it: same lanes, same addresses, program order.)  The
