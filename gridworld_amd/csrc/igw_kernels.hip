@@ -1593,12 +1593,12 @@ __global__ __launch_bounds__(BLOCK) void prepare_tasks_kernel(KParams p, int fir
     else zero_row_lds_wave(S);
     if (full_grid) row_to_lds_wave(F, full_grid + (size_t)i * STRIDE);
     wave_sync();
-    {   // block ids are 0..7 (env.py:85: Box(low=-1, high=7)): a cell with another id is read as empty, so that target
+    {   // block ids are 0..7 (env.py:85: Box(low=-1, high=7); 0..6 in a starting grid): a cell with another id is read as empty, so that target
         // size, bounding boxes and colour index of the row stay consistent, and the row is counted
         bool odd = false;
         for (int c = lane; c < CELLS; c += WAVE) {
             if ((unsigned)T[c] > 7u) { T[c] = 0; odd = true; }
-            if ((unsigned)S[c] > 7u) { S[c] = 0; odd = true; }
+            if ((unsigned)S[c] > 6u) { S[c] = 0; odd = true; }   // (a starting block is taken off the inventory: ids 1..6, env.py:243-246)
             if (full_grid && (unsigned)F[c] > 7u) { F[c] = 0; odd = true; }
         }
         if (__ballot(odd) && lane == 0) stat_add(p.stats, IGW_STAT_BAD_TASK, 1);

@@ -134,11 +134,12 @@ class VecGridWorld:
         inv = None
         if invariant is not None:
             inv = torch.as_tensor(np.broadcast_to(np.asarray(invariant, dtype=np.uint8), (T,)).copy(), device=dev)
-        for name, g in (('targets', tgt), ('starts', st)):
-            # block ids are 0..7 (the observation space's range, env.py:85); the C ABI counts offending rows
-            # (IGW_STAT_BAD_TASK) and never matches such a cell
-            if g is not None and g.numel() and (int(g.min()) < 0 or int(g.max()) > 7):
-                raise ValueError(f'{name}: block ids must be in 0..7')
+        for name, g, hi in (('targets', tgt, 7), ('starts', st, 6), ('full_grids', fg, 7)):
+            # block ids are 0..7 (the observation space's range, env.py:85); a starting block is taken off the inventory
+            # of its colour, ids 1..6 (env.py:243-246: the reference raises IndexError for 7).  The C ABI counts
+            # offending rows (IGW_STAT_BAD_TASK) and reads such a cell as empty.
+            if g is not None and g.numel() and (int(g.min()) < 0 or int(g.max()) > hi):
+                raise ValueError(f'{name}: block ids must be in 0..{hi}')
         if first < 0 or first + T > self.num_tasks:
             raise ValueError(f'task rows [{first}, {first + T}) do not fit the table of {self.num_tasks}')
         for name, g in (('starts', st), ('full_grids', fg)):

@@ -85,9 +85,10 @@ extern "C" {
                                * movement / camera values, camera deltas beyond +-IGW_CAMERA_MAX, inventory /
                                * hotbar ids outside 0..6 (the reference raises ValueError there,
                                * core/world.py:354-355) */
-#define IGW_STAT_BAD_TASK 6   /* task rows with a block id outside 0..7 in target, starting grid or full grid (the
-                               * ids of env.py:85): such a cell is read as empty (0), so the row stays consistent
-                               * (target size, bounding boxes, colour index) */
+#define IGW_STAT_BAD_TASK 6   /* task rows with a block id outside 0..7 in target or full grid (the ids of env.py:85)
+                               * or outside 0..6 in the starting grid (a starting block is taken off the inventory of
+                               * its colour, env.py:243-246; the reference raises IndexError for 7): such a cell is read
+                               * as empty (0), so the row stays consistent (target size, boxes, colour index) */
 /* largest |camera delta| per step (degrees; same bound as init_pose's yaw / pitch): the reference wraps yaw by
  * repeated subtraction of 360 (core/world.py:451-456), which never ends for a finite but huge value */
 #define IGW_CAMERA_MAX 1e6

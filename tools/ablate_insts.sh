@@ -6,7 +6,7 @@ OUT=gpurun_out/ablate
 mkdir -p $OUT
 export TMPDIR=/tmp IGW_DIAG=1
 for F in ${FLAGS:-0 1 2 4 6 7}; do
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/f$F -- python3 bench.py --no-cpu-baseline --no-fused --no-async --no-secondary --windows 2 --rehearsals 0 --mode ${MODE:-walking} --steps 100 --warmup 10 --debug-flags $F > $OUT/f$F.json 2> $OUT/f$F.log
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/f$F -- python3 bench.py --no-cpu-baseline --no-fused --no-async --no-secondary --no-api --windows 2 --rehearsals 0 --mode ${MODE:-walking} --steps 100 --warmup 10 --debug-flags $F > $OUT/f$F.json 2> $OUT/f$F.log
 done
 export FLAGS="${FLAGS:-0 1 2 4 6 7}"
 python3 - <<'PY'

@@ -4,8 +4,8 @@
 # condenses it into gpurun_out/profiles_<tag>/<tag>_{kernel_stats.csv,traffic.json,issue.json}
 # (copy those into profiles/ to commit them).
 set -u
-TAG=${1:-r02}
-ARGS=${2:-"--no-cpu-baseline --no-fused --no-async --no-secondary --windows 3 --rehearsals 1 --steps 200 --warmup 20"}
+TAG=${1:-r04}
+ARGS=${2:-"--no-cpu-baseline --no-fused --no-async --no-secondary --no-api --windows 3 --rehearsals 1 --steps 200 --warmup 20"}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
