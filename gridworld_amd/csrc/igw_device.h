@@ -284,7 +284,8 @@ struct Env {  // uniform across the lanes of a group
     double x, y, z, yaw, pitch, vy;
     int step_no, size, prev_size, max_int;
     uint32_t inv01, inv23, inv45;  // agent.inventory: 6 x int16, two per word (the record's layout)
-    int tis, active, target_size;
+    int tis_code;  // agent.time_int_steps as its code 0..3 = 2, 4, 8, 12 sub-steps (the record's encoding; tis_steps())
+    int active, target_size;
     int dirty;  // the histogram changed since max_int was last refreshed (a change with wrong_placement == 0)
     uint32_t episode;  // episodes started (aux record)
 };
@@ -295,35 +296,45 @@ __device__ __forceinline__ int inv_pick(uint32_t i01, uint32_t i23, uint32_t i45
     const uint32_t pair = i < 2 ? i01 : i < 4 ? i23 : i45;
     return (int)(int16_t)(pair >> ((i & 1) << 4));
 }
-__device__ __forceinline__ uint32_t inv_put(uint32_t pair, int i, int v) {
-    return (i & 1) ? (pair & 0x0000ffffu) | ((uint32_t)v << 16) : (pair & 0xffff0000u) | ((uint32_t)v & 0xffffu);
-}
 __device__ inline int inv_get(const Env& e, int i) {
     const uint32_t a = e.inv01, b = e.inv23, c = e.inv45;
     return inv_pick(a, b, c, i);
 }
+// inventory[i] += d as arithmetic on the packed word: the other half of the pair is kept by a bit-field insert, so a carry
+// out of the low half (-1 -> 0) cannot reach the high one.  d = 0 leaves everything as it is (callers pass a predicate).
 __device__ inline void inv_add(Env& e, int i, int d) {
     const uint32_t a = e.inv01, b = e.inv23, c = e.inv45;
-    const int v = inv_pick(a, b, c, i) + d;
-    e.inv01 = i < 2 ? inv_put(a, i, v) : a;
-    e.inv23 = (i >= 2 && i < 4) ? inv_put(b, i, v) : b;
-    e.inv45 = i >= 4 ? inv_put(c, i, v) : c;
+    const int hi = i >> 1;
+    const uint32_t sh = (uint32_t)(i & 1) << 4, mask = 0xffffu << sh;
+    const uint32_t pair = hi == 0 ? a : hi == 1 ? b : c;
+    const uint32_t sum = pair + ((uint32_t)d << sh);
+    const uint32_t np = (sum & mask) | (pair & ~mask);
+    e.inv01 = hi == 0 ? np : a;
+    e.inv23 = hi == 1 ? np : b;
+    e.inv45 = hi == 2 ? np : c;
 }
 __device__ inline int inv_lo(uint32_t pair) { return (int)(int16_t)(pair & 0xffffu); }
 __device__ inline int inv_hi(uint32_t pair) { return (int)pair >> 16; }
 constexpr uint32_t INV_FULL_PAIR = 20u | (20u << 16);  // Agent.__init__ / reset without a starting grid: 20 of each colour
 
+// time_int_steps of a code (2, 4, 8, 12) and the sub-step length 0.05 / time_int_steps as arithmetic on the code: the
+// three powers of two differ in the exponent field only (0.05 / 2 = 0x3f9999999999999a), 0.05 / 12 = 0x3f71111111111111
+__device__ inline int tis_steps(int code) { return code == 3 ? 12 : 2 << code; }
+__device__ inline double tis_dt(int code) {
+    const uint32_t hi = code == 3 ? 0x3f711111u : 0x3f999999u - ((uint32_t)code << 20);
+    const uint32_t lo = code == 3 ? 0x11111111u : 0x9999999au;
+    return __hiloint2double((int)hi, (int)lo);
+}
+
 // The raw words of the two records as the kernels move them: the agent record's fourth 16-byte piece and the aux record.
 __device__ inline void env_unpack_piece3(Env& e, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
     e.inv01 = w0; e.inv23 = w1; e.inv45 = w2;
     e.step_no = (int)(w3 & 0xffffu);
-    const int code = (int)((w3 >> 16) & 3u);
-    e.tis = code == 0 ? 2 : code == 1 ? 4 : code == 2 ? 8 : 12;
+    e.tis_code = (int)((w3 >> 16) & 3u);
     e.active = (int)((w3 >> 18) & 7u);
 }
 __device__ inline uint4 env_pack_piece3(const Env& e) {
-    const uint32_t code = e.tis == 2 ? 0u : e.tis == 4 ? 1u : e.tis == 8 ? 2u : 3u;
-    return make_uint4(e.inv01, e.inv23, e.inv45, (uint32_t)(e.step_no & 0xffff) | (code << 16) | ((uint32_t)(e.active & 7) << 18));
+    return make_uint4(e.inv01, e.inv23, e.inv45, (uint32_t)(e.step_no & 0xffff) | ((uint32_t)e.tis_code << 16) | ((uint32_t)(e.active & 7) << 18));
 }
 // aux record: {size | prev_size (+ dirty) << 16, max_int | target_size << 16, task, episode}
 __device__ inline void env_unpack_aux(Env& e, uint32_t a0, uint32_t a1, uint32_t a3) {
@@ -459,9 +470,12 @@ __device__ inline void sincos_deg(const TrigCtx& t, double deg, double& s, doubl
         igw_sincos(deg * PI_OVER_180, &s, &c);
         return;
     }
-    int id = (int)deg;
-    if ((double)id == deg && id >= 5 * IGW_LUT_K0 && id <= 5 * (IGW_LUT_K0 + IGW_LUT_N - 1) && (id % 5) == 0) {
-        int k = id / 5 - IGW_LUT_K0;
+    const int id = (int)deg;
+    // on the 5-degree lattice inside the table?  u = id - first angle; k = u / 5 by a 24-bit multiply (u <= 630 < 2^10:
+    // u * 0xCCCD >> 18 is exact there; v_mul_u32_u24 is full rate, the 32-bit multiply of a general id % 5 quarter rate)
+    const unsigned u = (unsigned)(id - 5 * IGW_LUT_K0);
+    const unsigned k = __umul24(u & 0x3ffu, 0xCCCDu) >> 18;
+    if ((double)id == deg && u <= 5u * (IGW_LUT_N - 1) && __umul24(k, 5u) == u) {
         c = t.lut[2 * k];
         s = t.lut[2 * k + 1];
     } else {

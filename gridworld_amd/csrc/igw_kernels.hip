@@ -132,11 +132,24 @@ struct ResetVals {
     bool has_start;
 };
 struct ResetMeta {   // bytes 0..47 and 64..79 of the metadata row, RAW: nothing is converted where it is loaded,
-    uint4 a, b, c, d;  // so nothing waits for these loads before reset_decode() -- the row's layout is in include/igw.h
+    vu4 a, b, c, d;    // so nothing waits for these loads before reset_decode() -- the row's layout is in include/igw.h
 };
 __device__ inline ResetMeta load_reset_meta(const TaskMeta* meta) {
-    const uint4* m = reinterpret_cast<const uint4*>(meta);
+    const vu4* m = reinterpret_cast<const vu4*>(meta);
     return ResetMeta{gload(m), gload(m + 1), gload(m + 2), gload(m + 4)};
+}
+// The same four loads issued early, for the lanes whose episode runs out in this step -- as inline assembly, so that the
+// compiler neither waits for them where the branch ends (a masked load's value is "needed" at the merge with the lanes
+// that did not load) nor zero-fills sixteen registers in every wavefront for those lanes.  The caller waits
+// (s_waitcnt vmcnt(0), behind the physics) before reset_decode().
+__device__ inline void prefetch_reset_meta(ResetMeta& r, const TaskMeta* meta) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:64"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d) : "v"(meta) : "memory");
+#else
+    r = load_reset_meta(meta);
+#endif
 }
 __device__ inline double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 __device__ inline ResetVals reset_decode(const ResetMeta& r) {
@@ -395,11 +408,16 @@ __device__ inline ActPre world_act_pre(const Grp<GS>& G, const KParams& p, Env& 
     const bool want_sight = a.want_sight;
     const bool strafing = s0 != 0.0 || s1 != 0.0;
     double strafe_deg = 0.0;
-    if (strafing) {  // math.degrees(math.atan2(*agent.strafe)), :176
+    if constexpr (MODE == MODE_WALK) {
+        // math.degrees(math.atan2(*agent.strafe)), :176.  Discrete(18) moves along one axis at a time: (s0, s1) =
+        // (-1, 0) -> -90, (1, 0) -> 90, (0, -1) -> 180, (0, 1) -> 0, exactly -- as a select of the high word (the low
+        // word of all four doubles is zero; nested ifs on doubles compile into exec-mask branches)
+        const uint32_t hi = s0 < 0.0 ? 0xc0568000u : s0 > 0.0 ? 0x40568000u : s1 < 0.0 ? 0x40668000u : 0u;
+        strafe_deg = __hiloint2double((int)hi, 0);
+    } else if (strafing) {
         if (!FLY && s1 == 0.0) strafe_deg = s0 < 0.0 ? -90.0 : 90.0;       // degrees(atan2(-+1, 0))
         else if (!FLY && s0 == 0.0) strafe_deg = s1 < 0.0 ? 180.0 : 0.0;   // degrees(atan2(0, -+1))
-        else if constexpr (MODE != MODE_WALK) strafe_deg = igw_atan2(s0, s1) * D180_OVER_PI;
-        // (Discrete(18) moves along one axis at a time: the two cases above are all it can produce)
+        else strafe_deg = igw_atan2(s0, s1) * D180_OVER_PI;
     }
     const bool want_pitch = want_sight || (FLY && strafing);
     double sp = 0.0, cp = 1.0, sy = 0.0, cy = 1.0, sx = 0.0, cx = 1.0;
@@ -443,28 +461,29 @@ template <int GS>
 __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* occ_s, const int8_t* grid_g, const ActPre& a,
                                             const Hit& h) {
     CellChange ch;
-    ch.idx = -1; ch.bit = 0; ch.old_val = 0; ch.new_val = 0; ch.occ_word = 0;
-    if (a.want_sight) {
-        if (a.add) {
-            if (h.hit && h.have_prev) {
-                if (inv_get(e, e.active - 1) > 0 && build_zone_i(h.px, h.py, h.pz)) {
-                    const double x = e.x, z = e.z;
-                    const double y = e.y - 1.0 + PAD;  // y - (PLAYER_HEIGHT - 1) + Agent.PAD
-                    const double bx = (double)h.px - 0.5, by = (double)h.py, bz = (double)h.pz - 0.5;
-                    const bool overlap = bx <= x && x <= bx + 1.0 && bz <= z && z <= bz + 1.0 &&
-                                         ((by <= y && y <= by + 1.0) || (by <= (y + 1.0) && (y + 1.0) <= by + 1.0));
-                    if (!overlap) {
-                        ch.idx = cell_of(h.px, h.py, h.pz);
-                        ch.bit = occ_bit_hbm(h.px, h.py, h.pz);
-                        ch.old_val = 0;  // `previous` is never occupied
-                        ch.new_val = e.active;
-                        inv_add(e, e.active - 1, -1);
-                    }
-                }
-            }
-        }
-        if (a.remove && h.hit && h.by != -2) {  // GREY / WHITE ground cannot be broken (:330)
-            const int cell = cell_of(h.bx, h.by, h.bz);
+    ch.old_val = 0; ch.occ_word = 0;
+    // Written flat -- one predicate per outcome, selects for the values: the reference's nest of five ifs (:312-332)
+    // compiles into five levels of exec-mask bookkeeping that nearly every wavefront walks through, because one of its
+    // sixteen envs usually places.  add and remove are never both set here (want_sight = add != remove).
+    //   place: a free cell in front of the hit (`previous`), inside the build zone, a block of the active colour left,
+    //          and the agent not standing in it
+    const double x = e.x, z = e.z;
+    const double y = e.y - 1.0 + PAD;  // y - (PLAYER_HEIGHT - 1) + Agent.PAD
+    const double bx = (double)h.px - 0.5, by = (double)h.py, bz = (double)h.pz - 0.5;
+    const bool overlap = bx <= x && x <= bx + 1.0 && bz <= z && z <= bz + 1.0 &&
+                         ((by <= y && y <= by + 1.0) || (by <= (y + 1.0) && (y + 1.0) <= by + 1.0));
+    const bool place = a.want_sight && a.add && h.hit && h.have_prev && inv_get(e, e.active - 1) > 0 &&
+                       build_zone_i(h.px, h.py, h.pz) && !overlap;
+    //   break: the block that was hit, unless it is the ground (GREY / WHITE cannot be broken, :330)
+    const bool brk = a.want_sight && a.remove && h.hit && h.by != -2;
+    const int cx = place ? h.px : h.bx, cy = place ? h.py : h.by, cz = place ? h.pz : h.bz;
+    const int cell = cell_of(cx, cy, cz);
+    ch.idx = (place || brk) ? cell : -1;
+    ch.bit = occ_bit_hbm(cx, cy, cz);
+    ch.new_val = place ? e.active : 0;   // (`previous` is never occupied: old_val = 0 for a placement)
+    inv_add(e, e.active - 1, place ? -1 : 0);
+    {
+        if (brk) {
             // colour of the block: the one int8 the physics ever needs (L1-bypassing load: a fused
             // rollout may have written this row earlier in the same launch)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -478,9 +497,6 @@ __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* 
             ch.old_val = (int)__hip_atomic_load(reinterpret_cast<const uint8_t*>(grid_g) + cell, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
 #endif
-            ch.idx = cell;
-            ch.bit = occ_bit_hbm(h.bx, h.by, h.bz);
-            ch.new_val = 0;
         }
         if (ch.idx >= 0) {
             wave_sync();
@@ -528,8 +544,8 @@ template <int GS, int MODE, bool PRIO = false>
 __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, const uint32_t* occ_s,
                                     const Motion& mv, bool boost = false) {
     constexpr bool FLY = MODE == MODE_FLY;
-    const int m = e.tis;
-    const double dt = m == 2 ? 0.05 / 2 : m == 4 ? 0.05 / 4 : m == 8 ? 0.05 / 8 : 0.05 / 12;
+    const int m = tis_steps(e.tis_code);
+    const double dt = tis_dt(e.tis_code);   // 0.05 / m
     [[maybe_unused]] double vy_pre = 0.0;
     // A walker that starts the step well inside the padded zone cannot leave it within the step: a step moves it by
     // at most 0.25 horizontally (speed 5 x dt 0.05) and 2.5 down / 0.35 up (terminal velocity 50, jump speed 6.93),
@@ -559,7 +575,7 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
             e.x = cx; e.y = cy; e.z = cz;
         }
     }
-    if (!FLY && !IGW_DIAG_FLAG(p, 4)) e.tis = vy_pre < -14.0 ? 12 : vy_pre < -10.0 ? 8 : vy_pre < -5.0 ? 4 : 2;
+    if (!FLY && !IGW_DIAG_FLAG(p, 4)) e.tis_code = (vy_pre < -5.0 ? 1 : 0) + (vy_pre < -10.0 ? 1 : 0) + (vy_pre < -14.0 ? 1 : 0);   // 2 / 4 / 8 / 12 sub-steps, :243-250
     if (FLY) e.vy = 0.0;
     // yaw wrap with strict comparisons (0 and 360 both survive), :451-456
     while (e.yaw > 360.0) e.yaw -= 360.0;
@@ -588,8 +604,8 @@ __device__ inline WalkAct parse_walking_discrete(int action) {
     WalkAct w;
     w.s0 = (double)pair(1, 3);             // 1 -> -1, 2 -> +1
     w.s1 = (double)pair(3, 7);             // 3 -> -1, 4 -> +1
-    w.cam0 = (double)(5 * pair(12, 25));   // 12 -> -5, 13 -> +5
-    w.cam1 = (double)(5 * pair(14, 29));   // 14 -> -5, 15 -> +5
+    w.cam0 = (double)__mul24(5, pair(12, 25));   // 12 -> -5, 13 -> +5  (v_mul_i32_i24: full rate; v_mul_lo_u32 is quarter rate)
+    w.cam1 = (double)__mul24(5, pair(14, 29));   // 14 -> -5, 15 -> +5
     w.dy = a == 5 ? 1.0 : 0.0;
     w.inventory = (unsigned)(a - 6) < 6u ? a - 5 : 0;
     w.remove = a == 16;
@@ -744,10 +760,12 @@ __device__ inline void occ_commit_const(uint32_t* occ_wave_s) {
     // and the zero words behind the variable part
     const int lane = __lane_id();
     const int q = lane & 3;
-    const uint4 pre = q == 0 ? make_uint4(occ_const_word(0), occ_const_word(1), occ_const_word(2), occ_const_word(3))
-                    : q == 1 ? make_uint4(occ_const_word(4), occ_const_word(5), occ_const_word(6), occ_const_word(7))
-                    : q == 2 ? make_uint4(occ_const_word(8), occ_const_word(9), occ_const_word(10), occ_const_word(11))
-                             : make_uint4(occ_const_word(12), occ_const_word(13), occ_const_word(14), occ_const_word(15));
+    // words 0..9 are zero, word 10 holds the first bits of the ground plane, words 11..15 are all ones: as masks of q
+    // (a four-way select of four-word constants compiles into exec-mask branches)
+    static_assert(occ_const_word(0) == 0u && occ_const_word(9) == 0u && occ_const_word(10) == 0xff800000u &&
+                  occ_const_word(11) == 0xffffffffu && occ_const_word(15) == 0xffffffffu, "constant prefix of the LDS occupancy row");
+    const uint32_t is3 = 0u - (uint32_t)(q == 3), ge2 = 0u - (uint32_t)(q >= 2);
+    const uint4 pre = make_uint4(is3, is3, is3 | (ge2 & occ_const_word(10)), ge2);
     static_assert(OCC_VAR0 == 16 && OCC_PITCH - OCC_VAR0 - OCC_WORDS == 8, "constant words are written as 4 + 2 pieces of 16 bytes");
 #pragma unroll
     for (int i0 = 0; i0 < EPW; i0 += WAVE / 4) {
@@ -1266,15 +1284,15 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // metadata row is fetched now (ResetMeta; with a task generator on the next task is not known yet)
     const bool ends = p.autoreset && e.step_no + 1 >= p.max_steps;
     const bool pre_ok = ends && !p.sample_tasks && !p.rt_enabled;
-    ResetMeta pre = {};
-    if (pre_ok) pre = load_reset_meta(p.task_meta + task);
+    ResetMeta pre;   // (registers of the lanes that do not prefetch stay undefined: tail_step loads for them if it has to)
+    if (pre_ok) prefetch_reset_meta(pre, p.task_meta + task);
     wave_sync();
     stamp(p, 1);
     if (IGW_DIAG_FLAG(p, 128)) return;  // diag 128: launch + the input burst, nothing else
     // a wave with an episode running out in this step has the reset to do on top: one priority level up
     const bool boost = __any(ends);
     prio_at<true, 1>(boost);
-    [[maybe_unused]] const int diag_m = e.tis;  // IGW_DIAG: sub-steps this env asked for
+    [[maybe_unused]] const int diag_m = tis_steps(e.tis_code);  // IGW_DIAG: sub-steps this env asked for
     e.step_no = min(e.step_no + 1, 65535);  // env.py:276
     CellChange ch;
     Motion mv;
@@ -1335,13 +1353,12 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     prio_at<true, 5>(boost);
     // Everything fetched early (break colour, start byte, the DMA of the changed envs) has to be in by now; the
     // physics had the time of its sub-steps to cover it.
-    if (chg_mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (chg_mask != 0 || boost) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (boost: a lane prefetched reset metadata)
     // ... and counts as consumed HERE: the counter is in order over loads and stores, so a first use at the end of
     // the step would wait for every store issued from now on (observations, histogram pieces) as well
     asm volatile("" : "+v"(start_val), "+v"(env_max_int));
-    // (the prefetched reset metadata too: raw words, decoded in tail_step)
-    asm volatile("" : "+v"(pre.a.x), "+v"(pre.a.y), "+v"(pre.a.z), "+v"(pre.a.w), "+v"(pre.b.x), "+v"(pre.b.y), "+v"(pre.b.z), "+v"(pre.b.w));
-    asm volatile("" : "+v"(pre.c.x), "+v"(pre.c.y), "+v"(pre.c.z), "+v"(pre.c.w), "+v"(pre.d.x), "+v"(pre.d.y), "+v"(pre.d.z));
+    // (the prefetched reset metadata too -- untracked loads: every use is ordered behind this point by the operands)
+    asm volatile("" : "+v"(pre.a), "+v"(pre.b), "+v"(pre.c), "+v"(pre.d));
     // The agent record is final (pose, inventory, step_no): its store is issued here -- behind that wait, so it does
     // not wait for it -- and completes in the shadow of the histogram update's LDS round trips, not at the very end of
     // the wave.  (A reset at the end of this step overwrites it: same lanes, same addresses, program order.)  The
