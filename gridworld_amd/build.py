@@ -19,9 +19,12 @@ SOURCES = ['igw_kernels.hip']
 HEADERS = ['igw_device.h', 'igw_trig.h', 'igw_trig_lut.h', 'igw_trig_tables.h',
            os.path.join('..', '..', 'include', 'igw.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-         '-fno-fast-math', '-Wall', '-Wno-unused-variable',
+         '-fno-fast-math', '-Wall', '-Wno-unused-variable', '-Wno-bitwise-instead-of-logical',
          # the step kernel's leading scalar arguments (the pointers of its input burst) arrive preloaded in SGPRs
-         '-mllvm', '-amdgpu-kernarg-preload-count=7']
+         '-mllvm', '-amdgpu-kernarg-preload-count=7',
+         # the counters are added by ONE lane per wavefront already (a ballot + popcount): the compiler's own wave-level
+         # reduction in front of every atomic only adds a dozen instructions
+         '-mllvm', '-amdgpu-atomic-optimizer-strategy=None']
 
 
 def hipcc():

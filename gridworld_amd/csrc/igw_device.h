@@ -414,15 +414,28 @@ __device__ inline void out_store(OutRec* o, const Env& e, bool reset_obs, float 
     st4(reinterpret_cast<uint4*>(o) + 3, out_piece_result(reward, done));
 }
 
+// A register holding ANY value, at no cost (LLVM: freeze poison).  For the lanes of a divergent branch that do not take it
+// when the others load something: merged with a zero, the loaded value would be needed (copied) where the branch ends --
+// and the wavefront would wait for the load there; merged with "any value" nothing is needed before the first real use.
+// (Not `int x;` read uninitialised: that is undefined behaviour, this is not.)
+__device__ inline uint32_t any_value_u() {
+    uint32_t v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = __builtin_nondeterministic_value(v);
+#endif
+    return v;
+}
+__device__ inline int any_value() { return (int)any_value_u(); }
+
 // ---------------------------------------------------------------- world queries
 
 // core/world.py:57-58
 __device__ inline bool build_zone_d(double x, double y, double z, double pad) {
     // -5-pad <= x <= 5+pad  <=>  |x| <= 5+pad (exact); likewise z
-    return __builtin_fabs(x) <= 5.0 + pad && __builtin_fabs(z) <= 5.0 + pad && -1.0 - pad <= y && y < 8.0 + pad;
+    return (__builtin_fabs(x) <= 5.0 + pad) & (__builtin_fabs(z) <= 5.0 + pad) & (-1.0 - pad <= y) & (y < 8.0 + pad);
 }
 __device__ inline bool build_zone_i(int x, int y, int z) {
-    return (unsigned)(x + 5) <= 10u && (unsigned)(z + 5) <= 10u && (unsigned)(y + 1) <= 8u;
+    return ((unsigned)(x + 5) <= 10u) & ((unsigned)(z + 5) <= 10u) & ((unsigned)(y + 1) <= 8u);
 }
 __device__ inline int cell_of(int x, int y, int z) { return (y + 1) * LEVEL + (x + 5) * 11 + (z + 5); }
 

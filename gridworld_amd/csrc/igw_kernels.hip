@@ -138,18 +138,16 @@ __device__ inline ResetMeta load_reset_meta(const TaskMeta* meta) {
     const vu4* m = reinterpret_cast<const vu4*>(meta);
     return ResetMeta{gload(m), gload(m + 1), gload(m + 2), gload(m + 4)};
 }
-// The same four loads issued early, for the lanes whose episode runs out in this step -- as inline assembly, so that the
-// compiler neither waits for them where the branch ends (a masked load's value is "needed" at the merge with the lanes
-// that did not load) nor zero-fills sixteen registers in every wavefront for those lanes.  The caller waits
-// (s_waitcnt vmcnt(0), behind the physics) before reset_decode().
-__device__ inline void prefetch_reset_meta(ResetMeta& r, const TaskMeta* meta) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:64"
-                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d) : "v"(meta) : "memory");
-#else
-    r = load_reset_meta(meta);
-#endif
+// "Any value" registers for the lanes that do not prefetch (any_value(): a register without an instruction): the merge
+// of a lane-masked load with such a value needs no copy, so the compiler neither waits for the loads where the branch
+// ends nor fills sixteen registers with zeros in every wavefront (what `ResetMeta pre = {}` cost).
+__device__ inline ResetMeta reset_meta_any() {
+    ResetMeta r;
+    r.a = vu4{any_value_u(), any_value_u(), any_value_u(), any_value_u()};
+    r.b = vu4{any_value_u(), any_value_u(), any_value_u(), any_value_u()};
+    r.c = vu4{any_value_u(), any_value_u(), any_value_u(), any_value_u()};
+    r.d = vu4{any_value_u(), any_value_u(), any_value_u(), any_value_u()};
+    return r;
 }
 __device__ inline double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 __device__ inline ResetVals reset_decode(const ResetMeta& r) {
@@ -360,12 +358,21 @@ __device__ __forceinline__ uint4 agent_piece(int q, double x, double y, double z
 struct CellChange {
     int idx;  // dense cell index; -1: grid unchanged this step
     int bit;  // the cell's bit in the HBM occupancy row
-    // old_val: the cell's colour before the step as the RAW zero-extended byte of a (possibly still pending) load:
-    // converting it where it is loaded would make the wave wait for the load there; old_colour() does it at the use
+    // old_val: for a break, the cell's colour before the step as the RAW zero-extended byte of a (possibly still pending)
+    // load: converting it where it is loaded would make the wave wait for the load there; old_colour() does it at the
+    // use.  Any value for the lanes that do not break.
     int old_val, new_val;
     uint32_t occ_word;  // the changed word of the occupancy row, as updated (leader lane; goes back to HBM at the end)
 };
-__device__ inline int old_colour(const CellChange& ch) { return (int)(int8_t)ch.old_val; }
+// (a placement fills a cell that was empty; only a break has loaded the colour.  The empty asm statement keeps the
+// conversion of the raw byte HERE: left alone the compiler hoists it to the load, and with it the wait for the load.)
+__device__ inline int old_colour(const CellChange& ch) {
+    int raw = ch.old_val;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(raw));
+#endif
+    return ch.new_val != 0 ? 0 : (int)(int8_t)raw;
+}
 
 struct Motion {  // get_motion_vector (core/world.py:163-201): constant over the sub-steps of one step
     double x, y, z;
@@ -387,9 +394,9 @@ __device__ inline ActPre world_act_pre(const Grp<GS>& G, const KParams& p, Env& 
     constexpr bool FLY = MODE == MODE_FLY;
     if (p.select_and_place && inventory != 0) { add = true; remove = false; }  // :444-446
     // movement, :344-356
-    if (dy != 0.0 && e.vy == 0.0) e.vy = JUMP_SPEED * dy;
-    if (FLY && dy == 0.0) e.vy = 0.0;
-    if (inventory >= 1 && inventory <= 6) e.active = inventory;
+    e.vy = ((dy != 0.0) & (e.vy == 0.0)) ? JUMP_SPEED * dy : e.vy;
+    if (FLY) e.vy = dy == 0.0 ? 0.0 : e.vy;
+    e.active = (unsigned)(inventory - 1) < 6u ? inventory : e.active;
     // move_camera, :338-342
     e.yaw = e.yaw + cam0;
     {
@@ -412,7 +419,11 @@ __device__ inline ActPre world_act_pre(const Grp<GS>& G, const KParams& p, Env& 
         // math.degrees(math.atan2(*agent.strafe)), :176.  Discrete(18) moves along one axis at a time: (s0, s1) =
         // (-1, 0) -> -90, (1, 0) -> 90, (0, -1) -> 180, (0, 1) -> 0, exactly -- as a select of the high word (the low
         // word of all four doubles is zero; nested ifs on doubles compile into exec-mask branches)
-        const uint32_t hi = s0 < 0.0 ? 0xc0568000u : s0 > 0.0 ? 0x40568000u : s1 < 0.0 ? 0x40668000u : 0u;
+        // (integer arithmetic on the two signs: a chain of selects on double comparisons compiles into branches again)
+        const int i0 = (int)s0, i1 = (int)s1;                       // -1, 0, 1
+        const uint32_t hi = (((uint32_t)(i0 < 0) << 31)             // -90: the sign
+                             | ((0u - (uint32_t)((i0 != 0) | (i1 < 0))) & 0x40568000u))   // 90 (and -90, 180): exponent and mantissa of 90
+                            + ((uint32_t)(i1 < 0) << 20);           // 180 = 2 x 90: one more in the exponent field
         strafe_deg = __hiloint2double((int)hi, 0);
     } else if (strafing) {
         if (!FLY && s1 == 0.0) strafe_deg = s0 < 0.0 ? -90.0 : 90.0;       // degrees(atan2(-+1, 0))
@@ -457,7 +468,9 @@ __device__ inline ActPre world_act_pre(const Grp<GS>& G, const KParams& p, Env& 
 
 // place_or_remove_block, :312-332, given the result of the ray march.  For a break, ch.old_val is the pending
 // colour load of the block that was hit: nothing here waits for it (finish_break consumes it after the physics).
-template <int GS>
+// FUSED: the caller is the fused loop, where an earlier step of the SAME launch may have written the row (the colour is
+// then read past this CU's L1).
+template <int GS, bool FUSED = true>
 __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* occ_s, const int8_t* grid_g, const ActPre& a,
                                             const Hit& h) {
     CellChange ch;
@@ -470,12 +483,14 @@ __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* 
     const double x = e.x, z = e.z;
     const double y = e.y - 1.0 + PAD;  // y - (PLAYER_HEIGHT - 1) + Agent.PAD
     const double bx = (double)h.px - 0.5, by = (double)h.py, bz = (double)h.pz - 0.5;
-    const bool overlap = bx <= x && x <= bx + 1.0 && bz <= z && z <= bz + 1.0 &&
-                         ((by <= y && y <= by + 1.0) || (by <= (y + 1.0) && (y + 1.0) <= by + 1.0));
-    const bool place = a.want_sight && a.add && h.hit && h.have_prev && inv_get(e, e.active - 1) > 0 &&
-                       build_zone_i(h.px, h.py, h.pz) && !overlap;
+    // (& and |, not && and ||: every operand is cheap and side-effect free, and short-circuit evaluation of floating-point
+    // comparisons compiles into exec-mask branches)
+    const bool overlap = (bx <= x) & (x <= bx + 1.0) & (bz <= z) & (z <= bz + 1.0) &
+                         (((by <= y) & (y <= by + 1.0)) | ((by <= (y + 1.0)) & ((y + 1.0) <= by + 1.0)));
+    const bool place = a.want_sight & a.add & h.hit & h.have_prev & (inv_get(e, e.active - 1) > 0) &
+                       build_zone_i(h.px, h.py, h.pz) & !overlap;
     //   break: the block that was hit, unless it is the ground (GREY / WHITE cannot be broken, :330)
-    const bool brk = a.want_sight && a.remove && h.hit && h.by != -2;
+    const bool brk = a.want_sight & a.remove & h.hit & (h.by != -2);
     const int cx = place ? h.px : h.bx, cy = place ? h.py : h.by, cz = place ? h.pz : h.bz;
     const int cell = cell_of(cx, cy, cz);
     ch.idx = (place || brk) ? cell : -1;
@@ -483,20 +498,21 @@ __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* 
     ch.new_val = place ? e.active : 0;   // (`previous` is never occupied: old_val = 0 for a placement)
     inv_add(e, e.active - 1, place ? -1 : 0);
     {
-        if (brk) {
-            // colour of the block: the one int8 the physics ever needs (L1-bypassing load: a fused
-            // rollout may have written this row earlier in the same launch)
-#if defined(__HIP_DEVICE_COMPILE__)
-            // ... as inline assembly: the compiler does not know that a load is pending on ch.old_val, so nothing waits
-            // for it here.  (Written as C++, the masked load's value is needed where this branch ends -- the merge with
-            // the 0 of the lanes that do not break: s_waitcnt vmcnt(0) eleven instructions behind the load, a full
-            // memory round trip in the middle of the step for every wavefront with a break, one in five.)
-            // finish_break waits for it where the colour is needed, behind the physics.
-            asm volatile("global_load_ubyte %0, %1, off sc1" : "+v"(ch.old_val) : "v"(reinterpret_cast<const uint8_t*>(grid_g) + cell) : "memory");
-#else
-            ch.old_val = (int)__hip_atomic_load(reinterpret_cast<const uint8_t*>(grid_g) + cell, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-#endif
+        // colour of the block: the one int8 the physics ever needs (L1-bypassing load: a fused rollout may have written
+        // this row earlier in the same launch).  Under a WAVE-UNIFORM branch, by every lane (a lane that does not break
+        // reads the first byte of its own row), into a register that holds any value otherwise: no lane-masked merge at
+        // the end of the branch, so no copy of the loaded value there and no wait for it -- as a masked load merged with a
+        // zero the compiler put s_waitcnt vmcnt(0) eleven instructions behind it: a memory round trip in the middle of
+        // the step for every wavefront with a break, one in five.  old_colour() reads it only for a break.  (An
+        // untracked inline-asm load, waited for behind the physics, is NOT safe: the compiler may copy the destination
+        // register while the load is in flight, and with one lane per env it did.)
+        ch.old_val = any_value();
+        if (__any(brk)) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(grid_g) + (brk ? cell : 0);
+            // (the atomic byte load is legalised as a 16-bit load + v_and, which again needs the value at once: the step
+            // kernel, whose rows were written by earlier launches, reads with a plain load)
+            if constexpr (FUSED) ch.old_val = (int)__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ch.old_val = (int)gload(src);
         }
         if (ch.idx >= 0) {
             wave_sync();
@@ -531,9 +547,6 @@ __device__ inline CellChange world_act(const Grp<GS>& G, const KParams& p, Env& 
 // remove_block's inventory refund (env.py:146-153 via the on_remove callback), once the colour has arrived
 __device__ inline void finish_break(Env& e, CellChange& ch) {
     if (ch.idx >= 0 && ch.new_val == 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ch.old_val) : : "memory");   // the colour load of world_act_post
-#endif
         const int texture = old_colour(ch);
         if (texture >= 1 && texture <= 6) inv_add(e, texture - 1, 1);
     }
@@ -553,7 +566,7 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
     // wavefront -- agents return to the centre every episode -- the sub-steps skip the four comparisons of
     // build_zone (their outcome is known: inside) and the selects behind them.
     bool inside = false;
-    if constexpr (!FLY) inside = __all(__builtin_fabs(e.x) < 6.0 && __builtin_fabs(e.z) < 6.0 && e.y >= -0.5 && e.y < 9.0);
+    if constexpr (!FLY) inside = __all((__builtin_fabs(e.x) < 6.0) & (__builtin_fabs(e.z) < 6.0) & (e.y >= -0.5) & (e.y < 9.0));
     for (int i = 0; i < (IGW_DIAG_FLAG(p, 4) ? 0 : m); i++) {  // _update, :222-262
         if (i == 1) prio_at<PRIO, 4>(boost);
         const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
@@ -1098,8 +1111,12 @@ __device__ inline KParams reset_params(const KParams& p) {
     return q;
 }
 
-// The end of a step: reward / done, the in-step reset, the last stores.  size_in: SizeReward.size as the step loaded it
-// (the aux record goes back to memory only when something in it changed).
+// The end of a step: reward / done, the in-step reset of the episodes that ended, the last stores, the counters.
+// Two copies of the stores, chosen by a wave-uniform branch: the fifteen wavefronts in sixteen that reset nothing must not
+// run BEHIND the reset path -- where the two paths join, the compiler is conservative: an s_waitcnt vmcnt(0) for a load
+// that only the reset path issues, which on the common path waits for the acknowledgement of every store of the
+// wavefront, and a dozen copies that merge the reset values with the step's.  size_in: SizeReward.size as the step loaded
+// it (the aux record goes back to memory only when it changed).
 template <int GS, int MODE, bool EXTRA>
 __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn& a, BlockShared<GS>& sh, int wave, int env,
                                  bool active, Env& e, const CellChange& ch, int task, int env_max_int, int size_new, int mi,
@@ -1107,31 +1124,37 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
                                  [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok, const TailParams& tp, int size_in) {
     const StepOut o = finish_step(tp, e, env_max_int, size_new, mi);
     const bool do_reset = active && o.done && tp.autoreset;
-    const uint4 ob = out_piece_step(e, G.gl & 3);   // obs of this step (env.py:281-289), before a reset changes the registers
-    uint32_t ep = e.episode;
-    const int task_old = task;
-    int generated_size = -1;
-    bool has_start = false;
-    ResetVals rv = {};
-    if (__any(do_reset)) {   // (one wavefront in sixteen)
-        // The kernel parameters the reset path needs, read from the kernarg segment in ONE batch: read where they are
-        // used, each of eight scalar loads was followed by its own s_waitcnt -- eight scalar-memory round trips one
-        // after the other in the wavefronts that already have the most to do.
-        KParams rq;
-        if constexpr (EXTRA) rq = p;   // (the generator and the episode log use most of them)
-        else rq = reset_params(p);
-        const KParams& rp = rq;
-        if (do_reset) {
-            ep = next_task(rp, env, e, task);  // the next episode's task (task generators on the device)
-            // (an episode that ends early -- target completed -- or a task that was only just chosen: fetched now)
-            if (!pre_ok) rm = load_reset_meta(rp.task_meta + task);
-            rv = reset_decode(rm);
-            has_start = !rp.rt_enabled && rv.has_start;
+    // the stores of an env whose episode goes on (`keep`); the counters of the wavefront
+    const auto step_stores = [&](bool keep) {
+        if constexpr (EXTRA) {
+            if (keep && p.traj && env < p.traj_n && G.gl == 0) write_trajectory<MODE>(p, a, env, task, e.episode, e, ch, o, false, task);
         }
-        resolve_resets<GS, EXTRA>(G, rp, do_reset, env, task, has_start, ep, nullptr,
-                                  reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size);
-    }
-    prio_at<true, 7>(boost);
+        if (keep && G.gl == 0 && ch.idx >= 0) {
+            gstore(grid_g + ch.idx, (int8_t)ch.new_val);
+            gstore(tp.occ + (size_t)env * OCC_WORDS + (ch.bit >> 5), ch.occ_word);
+        }
+        const bool aux_dirty = changed || e.size != size_in;
+        if constexpr (GS >= 4) {
+            // the whole output record in ONE store instruction: observations (env.py:281-289) by lanes 0..2, reward + done
+            // by lane 3
+            if (keep && G.gl < 4 && !IGW_DIAG_FLAG(p, 16))
+                st4(reinterpret_cast<uint4*>(tp.out + env) + G.gl, G.gl == 3 ? out_piece_result((float)o.reward, o.done) : out_piece_step(e, G.gl));
+            if (keep && G.gl == 0 && aux_dirty) st4(tp.aux + env, env_pack_aux(e, task));
+        } else if (keep && G.gl == 0) {
+            if (!IGW_DIAG_FLAG(p, 16)) out_store(tp.out + env, e, false, (float)o.reward, o.done);
+            if (aux_dirty) aux_store(e, task, tp.aux + env);
+        }
+    };
+    const auto counters = [&]() {   // one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
+        const uint64_t m_need = __ballot(need && active && G.gl == 0), m_cell = __ballot(ch.idx >= 0 && active && G.gl == 0),
+                       m_reset = __ballot(do_reset && G.gl == 0);
+        if ((m_need | m_cell | m_reset) != 0 && tp.stats != nullptr && G.lane == 0) {
+            unsigned long long* st = tp.stats + (blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8;
+            if (m_need) counter_add(st + IGW_STAT_CHANGED, (unsigned long long)__builtin_popcountll(m_need));
+            if (m_cell) counter_add(st + IGW_STAT_RESCANS, (unsigned long long)__builtin_popcountll(m_cell));
+            if (m_reset) counter_add(st + IGW_STAT_RESETS, (unsigned long long)__builtin_popcountll(m_reset));
+        }
+    };
 #ifdef IGW_DIAG
     {
         const unsigned long long n_ch = __builtin_popcountll(__ballot(changed && G.gl == 0));
@@ -1140,42 +1163,55 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
         stamp_features(p, n_ch | (n_rt << 16) | ((unsigned long long)wave_max_i32(diag_m) << 24) | (n_hit << 32));
     }
 #endif
-    if (!active) return;
-    if constexpr (EXTRA) {
-        if (p.traj && env < p.traj_n && G.gl == 0) write_trajectory<MODE>(p, a, env, task_old, ep, e, ch, o, do_reset, task);
+    if (!__any(do_reset)) {   // fifteen wavefronts in sixteen
+        step_stores(active);
+        counters();
+        stamp(p, 6);
+        return;
     }
-    const bool aux_dirty = changed || do_reset || e.size != size_in;
-    if (do_reset) reset_env_regs(e, rv, false, generated_size);
-    if (G.gl == 0 && ch.idx >= 0 && !do_reset) {
-        gstore(grid_g + ch.idx, (int8_t)ch.new_val);
-        gstore(tp.occ + (size_t)env * OCC_WORDS + (ch.bit >> 5), ch.occ_word);
+    // ---- a wavefront with an episode that ended: the reset first (its loads go out before the stores), then the stores
+    // The kernel parameters the reset path needs, read from the kernarg segment in ONE batch: read where they are used,
+    // each of eight scalar loads was followed by its own s_waitcnt -- eight scalar-memory round trips one after the other
+    // in the wavefronts that already have the most to do.
+    KParams rq;
+    if constexpr (EXTRA) rq = p;   // (the generator and the episode log use most of them)
+    else rq = reset_params(p);
+    const KParams& rp = rq;
+    uint32_t ep = e.episode;
+    const int task_old = task;
+    int generated_size = -1;
+    bool has_start = false;
+    ResetVals rv = {};
+    if (do_reset) {
+        ep = next_task(rp, env, e, task);  // the next episode's task (task generators on the device)
+        // (an episode that ends early -- target completed -- or a task that was only just chosen: fetched now)
+        if (!pre_ok) rm = load_reset_meta(rp.task_meta + task);
+        rv = reset_decode(rm);
+        has_start = !rp.rt_enabled && rv.has_start;
     }
-    if constexpr (GS >= 4) {
-        if (G.gl < 4) {
-            // a reset's agent record goes the way the step's went (same lane -> same address: program order)
-            if (do_reset) st4(reinterpret_cast<uint4*>(tp.agent + env) + G.gl, agent_piece(G.gl, e.x, e.y, e.z, e.yaw, e.pitch, e.vy, env_pack_piece3(e)));
-            // the whole output record in ONE store instruction: observations (of the reset, if one happened) by lanes
-            // 0..2, reward + done by lane 3
-            if (!IGW_DIAG_FLAG(p, 16))
-                st4(reinterpret_cast<uint4*>(tp.out + env) + G.gl,
-                    G.gl == 3 ? out_piece_result((float)o.reward, o.done) : do_reset ? out_piece_reset(e, G.gl) : ob);
+    resolve_resets<GS, EXTRA>(G, rp, do_reset, env, task, has_start, ep, nullptr,
+                              reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size);
+    prio_at<true, 7>(boost);
+    step_stores(active && !do_reset);
+    if (do_reset) {
+        if constexpr (EXTRA) {
+            if (p.traj && env < p.traj_n && G.gl == 0) write_trajectory<MODE>(p, a, env, task_old, ep, e, ch, o, true, task);
         }
-        if (G.gl == 0 && aux_dirty) st4(tp.aux + env, env_pack_aux(e, task));
-    } else if (G.gl == 0) {
-        if (do_reset) env_store(e, tp.agent + env);
-        if (!IGW_DIAG_FLAG(p, 16)) out_store(tp.out + env, e, do_reset, (float)o.reward, o.done);
-        if (aux_dirty) aux_store(e, task, tp.aux + env);
-    }
-    {   // the wave's counters: one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
-        const uint64_t m_need = __ballot(need && G.gl == 0), m_cell = __ballot(ch.idx >= 0 && G.gl == 0),
-                       m_reset = __ballot(do_reset && G.gl == 0);
-        if ((m_need | m_cell | m_reset) != 0 && tp.stats != nullptr && G.lane == 0) {
-            unsigned long long* st = tp.stats + (blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8;
-            if (m_need) counter_add(st + IGW_STAT_CHANGED, (unsigned long long)__builtin_popcountll(m_need));
-            if (m_cell) counter_add(st + IGW_STAT_RESCANS, (unsigned long long)__builtin_popcountll(m_cell));
-            if (m_reset) counter_add(st + IGW_STAT_RESETS, (unsigned long long)__builtin_popcountll(m_reset));
+        reset_env_regs(e, rv, false, generated_size);
+        if constexpr (GS >= 4) {
+            if (G.gl < 4) {   // the reset's agent record goes the way the step's went (same lane -> same address: program order)
+                st4(reinterpret_cast<uint4*>(tp.agent + env) + G.gl, agent_piece(G.gl, e.x, e.y, e.z, e.yaw, e.pitch, e.vy, env_pack_piece3(e)));
+                if (!IGW_DIAG_FLAG(p, 16))   // the whole output record: the reset's observations, the step's reward + done
+                    st4(reinterpret_cast<uint4*>(tp.out + env) + G.gl, G.gl == 3 ? out_piece_result((float)o.reward, o.done) : out_piece_reset(e, G.gl));
+            }
+            if (G.gl == 0) st4(tp.aux + env, env_pack_aux(e, task));
+        } else if (G.gl == 0) {
+            env_store(e, tp.agent + env);
+            if (!IGW_DIAG_FLAG(p, 16)) out_store(tp.out + env, e, true, (float)o.reward, o.done);
+            aux_store(e, task, tp.aux + env);
         }
     }
+    counters();
     stamp(p, 6);
 }
 
@@ -1284,8 +1320,14 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // metadata row is fetched now (ResetMeta; with a task generator on the next task is not known yet)
     const bool ends = p.autoreset && e.step_no + 1 >= p.max_steps;
     const bool pre_ok = ends && !p.sample_tasks && !p.rt_enabled;
-    ResetMeta pre;   // (registers of the lanes that do not prefetch stay undefined: tail_step loads for them if it has to)
-    if (pre_ok) prefetch_reset_meta(pre, p.task_meta + task);
+    // (the lanes that do not prefetch: tail_step loads for them if it has to.  Their registers hold "any value", and the
+    // cheapest any value is one that is already in registers and dead: the words of the input burst)
+    ResetMeta pre = reset_meta_any();
+    if constexpr (GS == 4 && REC_SPREAD) {
+        const auto as4 = [](const uint4& v) { return vu4{v.x, v.y, v.z, v.w}; };
+        pre = ResetMeta{as4(rec_piece), as4(occ_in.v[0]), as4(occ_in.v[1]), as4(occ_in.v[2])};
+    }
+    if (pre_ok) pre = load_reset_meta(p.task_meta + task);
     wave_sync();
     stamp(p, 1);
     if (IGW_DIAG_FLAG(p, 128)) return;  // diag 128: launch + the input burst, nothing else
@@ -1334,7 +1376,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     h.hit = false; h.have_prev = false;
     h.bx = h.by = h.bz = h.px = h.py = h.pz = 0;
     if (ap.want_sight) h = hit_test<GS, true>(G, occ_s, e.x, e.y, e.z, ap.vx, ap.vy, ap.vz, boost, sh.ws[wave].hist[0]);
-    ch = world_act_post<GS>(G, e, occ_s, grid_g, ap, h);
+    ch = world_act_post<GS, false>(G, e, occ_s, grid_g, ap, h);
     // issued here, consumed after the histogram update
     int start_val = 0, env_max_int = 0;
     if (ch.idx >= 0) start_val = p.task_start[(size_t)task * STRIDE + ch.idx];
@@ -1353,11 +1395,11 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     prio_at<true, 5>(boost);
     // Everything fetched early (break colour, start byte, the DMA of the changed envs) has to be in by now; the
     // physics had the time of its sub-steps to cover it.
-    if (chg_mask != 0 || boost) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (boost: a lane prefetched reset metadata)
+    if (chg_mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ... and counts as consumed HERE: the counter is in order over loads and stores, so a first use at the end of
     // the step would wait for every store issued from now on (observations, histogram pieces) as well
     asm volatile("" : "+v"(start_val), "+v"(env_max_int));
-    // (the prefetched reset metadata too -- untracked loads: every use is ordered behind this point by the operands)
+    // (the prefetched reset metadata too: raw words, decoded in tail_step)
     asm volatile("" : "+v"(pre.a), "+v"(pre.b), "+v"(pre.c), "+v"(pre.d));
     // The agent record is final (pose, inventory, step_no): its store is issued here -- behind that wait, so it does
     // not wait for it -- and completes in the shadow of the histogram update's LDS round trips, not at the very end of
