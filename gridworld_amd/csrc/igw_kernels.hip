@@ -809,11 +809,20 @@ struct RawAct {
 template <int GS>
 __device__ inline void load_fly_spread(const ActIn& a, int env, int gl, RawAct& r) {
     const int q = gl & 3;
-    const void* p1 = q < 3 ? (const void*)(a.movement + 3 * (size_t)env + q) : (const void*)(a.camera + 2 * (size_t)env);
-    const void* p2 = q == 0 ? (const void*)(a.camera + 2 * (size_t)env + 1)
-                   : q == 1 ? (const void*)(a.inventory + env) : (const void*)(a.placement + env);
-    r.w1 = *reinterpret_cast<const uint32_t*>(p1);
-    r.w2 = *reinterpret_cast<const uint32_t*>(p2);
+    // The lane's two addresses as selects on 32-bit halves and a byte offset (a select between 64-bit pointers compiles
+    // into exec-mask branches): lane q reads movement[q] (q < 3) or camera[0], then camera[1] / inventory / placement.
+    const auto pick = [](bool c, const void* x, const void* y) {
+        const uint64_t ux = (uint64_t)(uintptr_t)x, uy = (uint64_t)(uintptr_t)y;
+        const uint32_t lo = c ? (uint32_t)ux : (uint32_t)uy, hi = c ? (uint32_t)(ux >> 32) : (uint32_t)(uy >> 32);
+        return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    };
+    const uint32_t e4 = 4u * (uint32_t)env;
+    const char* b1 = pick(q < 3, a.movement, a.camera);
+    const uint32_t o1 = q < 3 ? 3u * e4 + 4u * (uint32_t)q : 2u * e4;
+    const char* b2 = pick(q == 0, a.camera, pick(q == 1, a.inventory, a.placement));
+    const uint32_t o2 = q == 0 ? 2u * e4 + 4u : e4;
+    r.w1 = *reinterpret_cast<const uint32_t*>(b1 + o1);
+    r.w2 = *reinterpret_cast<const uint32_t*>(b2 + o2);
 }
 __device__ inline void fly_fields(RawAct& r) {
     r.f[0] = __uint_as_float((uint32_t)dpp_quad<QUAD_BCAST0>((int)r.w1));
