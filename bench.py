@@ -193,7 +193,7 @@ def cpu_baseline(seed):
 
     def leg(mode, budget_s):
         kw = dict(size_reward=False) if mode == 'walking' else dict(size_reward=False, action_space='flying')
-        n = int(min(16384, max(256, 64 * cores)))
+        n = int(min(16384, max(256, 1024 * cores)))   # (about 10 s of CPU work on the box's 16 granted cores)
         tg = workloads.rt20(n, seed).numpy()
         b = O.OracleBatch(n, **kw)
         b.set_tasks(tg)
@@ -600,10 +600,12 @@ def roofline_of(r, m, lanes, has_start_frac=0.0):
     roof['hbm_frac_measured'] = roof['hbm_measured_frac']
     roof['note'] = ('`frac` follows the SURVEY 8(d) convention (the 1,089-byte int8 grid priced every step); this design keeps a '
                     '192-byte occupancy bitmap of it and streams ~0.5 KB per env-step, so `frac` rises with any speed-up and '
-                    'exceeds 1 at 524,288 envs per launch (1.10-1.15) although no work is skipped -- the bytes are not moved. '
-                    'The kernel is bound by per-wavefront dependent-issue latency: `issue_util` = VALU-issue utilisation of a '
-                    'SIMD (instruction count of the committed SQ profile x this run\'s kernel time), `hbm_frac_measured` = PMC '
-                    'bytes of the committed profile / this run\'s kernel time / peak.')
+                    'exceeds 1 at 524,288 envs per launch (1.2) although no work is skipped -- the bytes are not moved. '
+                    'The kernel is bound by instruction issue: a wavefront issues about one instruction per 11 cycles (its '
+                    'next one depends on the last) and the four wavefronts of a SIMD keep its vector ALU busy for `issue_util` '
+                    'of the launch (VALU instructions per wavefront of the committed SQ profile x 4 cycles x 4 wavefronts over '
+                    'this run\'s kernel time); `hbm_frac_measured` = PMC bytes of the committed profile / this run\'s kernel '
+                    'time / peak.')
     return roof, iss
 
 
