@@ -32,7 +32,7 @@ constexpr int WAVE = 64;
 // 2 ray march: coordinates done, 3 place / break done, 4 first physics sub-step done, 5 physics done,
 // 6 histogram update done, 7 resets done.
 #ifndef IGW_PRIO_MAP
-#define IGW_PRIO_MAP 0x00111233   /* round 3, re-tuned on the final kernel: 0x00112233 +0.3 % walking, +0.7 % flying */
+#define IGW_PRIO_MAP 0x00011223   /* re-tuned on the round-4 kernel (profiles/r04_ab_variants.txt): round 3's 0x00111233 +0.6 % walking, +1.0 % flying */
 #endif
 template <bool ON, int PT>
 __device__ inline void prio_at(bool boost = false) {
