@@ -357,6 +357,8 @@ __device__ __forceinline__ uint4 agent_piece(int q, double x, double y, double z
 
 struct CellChange {
     int idx;  // dense cell index; -1: grid unchanged this step
+    int lvl;  // ... its y level (idx / 121) and (x + 5) | (z + 5) << 4 within the level: known where the cell is chosen,
+    int xz;   //     so nothing downstream divides
     int bit;  // the cell's bit in the HBM occupancy row
     // old_val: for a break, the cell's colour before the step as the RAW zero-extended byte of a (possibly still pending)
     // load: converting it where it is loaded would make the wave wait for the load there; old_colour() does it at the
@@ -494,6 +496,8 @@ __device__ inline CellChange world_act_post(const Grp<GS>& G, Env& e, uint32_t* 
     const int cx = place ? h.px : h.bx, cy = place ? h.py : h.by, cz = place ? h.pz : h.bz;
     const int cell = cell_of(cx, cy, cz);
     ch.idx = (place || brk) ? cell : -1;
+    ch.lvl = cy + 1;
+    ch.xz = (cx + 5) | ((cz + 5) << 4);
     ch.bit = occ_bit_hbm(cx, cy, cz);
     ch.new_val = place ? e.active : 0;   // (`previous` is never occupied: old_val = 0 for a placement)
     inv_add(e, e.active - 1, place ? -1 : 0);
@@ -900,7 +904,7 @@ __device__ inline uint64_t prefetch_changes(const Grp<GS>& G, const KParams& p, 
         if (m) {
             const int l = next_leader(m);
             dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
-                                     __builtin_amdgcn_readlane(ch.idx, l) / LEVEL);
+                                     __builtin_amdgcn_readlane(ch.lvl, l));
         }
     }
     return mask;
@@ -936,9 +940,8 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         int a = old_colour(ch) - start_val, b = ch.new_val - start_val;  // old / new synthetic colour, a != b
         a = (a < -7 || a > 7) ? 0 : a;
         b = (b < -7 || b > 7) ? 0 : b;
-        const int rem = ch.idx % LEVEL;
         *reinterpret_cast<uint2*>(ws.chg[rank]) =
-            make_uint2((uint32_t)env, (uint32_t)(rem / 11) | ((uint32_t)(rem % 11) << 4) | ((uint32_t)(a & 15) << 8) | ((uint32_t)(b & 15) << 12));
+            make_uint2((uint32_t)env, (uint32_t)ch.xz | ((uint32_t)(a & 15) << 8) | ((uint32_t)(b & 15) << 12));
     }
     const int slot = lane >> 4, sub = lane & 15, mi = sub >> 2, q = lane & 3;
     uint64_t m = mask;
@@ -952,7 +955,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 // more changed envs than scratch rows: the later chunks are fetched only now (rare)
                 if (base > 0)
                     dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
-                                             __builtin_amdgcn_readlane(ch.idx, l) / LEVEL);
+                                             __builtin_amdgcn_readlane(ch.lvl, l));
             }
         }
         // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks wait here
@@ -983,11 +986,13 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 const int cell = blk[LVL_CELLS + (dec ? oa0 + idx : ob0 + (idx - na))];
                 const int tx = cell >> 4, tz = cell & 15;
                 // rotation q of target cell (x, z): (x,z) -> (z, 10-x) -> (10-x, 10-z) -> (10-z, x)
-                const int rx = q == 0 ? tx : q == 1 ? tz : q == 2 ? 10 - tx : 10 - tz;
-                const int rz = q == 0 ? tz : q == 1 ? 10 - tx : q == 2 ? 10 - tz : tx;
+                // (as two selects each on predicates of the lane's rotation: a four-way select chain compiles into branches)
+                const int bx = (q & 1) ? tz : tx, bz = (q & 1) ? tx : tz;
+                const int rx = q >= 2 ? 10 - bx : bx;
+                const int rz = (q == 1 || q == 2) ? 10 - bz : bz;
                 const int u = rx - gx - dxlo, v = rz - gz - dzlo;
                 if ((unsigned)u <= (unsigned)(xmin - dxlo) && (unsigned)v <= (unsigned)(zmin - dzlo)) {  // (extents <= 10: both bounds >= 0)
-                    const int bin = q * 121 + u * 11 + v;
+                    const int bin = q * 121 + __mul24(u, 11) + v;
                     const uint32_t one = 1u << (16 * (bin & 1));
                     atomicAdd(&ws.hist[sl][bin >> 1], dec ? 0u - one : one);
                 }
