@@ -346,6 +346,17 @@ __device__ inline void reset_rows_wave(const KParams& p, int env, int task, bool
     gstore(dh + lane, zero);
 }
 
+// The same for the ONE env per wavefront whose starting row the step fetched ahead (start_row_prefetch): the grid row is
+// in LDS, the occupancy words in a register of lanes 0..47 -- stores only, no memory round trip at the end of the step.
+__device__ inline void reset_rows_staged(const KParams& p, int env, const uint32_t* row_s, const uint32_t* tail_s, uint32_t occ_w) {
+    const int lane = __lane_id();
+    uint4* dg = reinterpret_cast<uint4*>(p.grid + (size_t)env * STRIDE);
+    gstore(dg + lane, reinterpret_cast<const uint4*>(row_s)[lane]);
+    if (lane < CHUNKS - WAVE) gstore(dg + WAVE + lane, reinterpret_cast<const uint4*>(tail_s)[lane]);
+    if (lane < OCC_WORDS) gstore(p.occ + (size_t)env * OCC_WORDS + lane, occ_w);
+    gstore(reinterpret_cast<uint4*>(p.hist + (size_t)env * HIST_ROW) + lane, make_uint4(0, 0, 0, 0));
+}
+
 // The agent record as its four 16-byte pieces, lane q of the env's (first) quad stores piece q: ONE store instruction
 // for the whole record.  (By value: a select between FIELDS of the env struct becomes a load from a selected address
 // and parks the struct in scratch memory.)
@@ -1030,7 +1041,8 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
 template <int GS, bool RT>
 __device__ inline void resolve_resets(const Grp<GS>& G, const KParams& p, bool do_reset, int env, int task,
                                       bool has_start, uint32_t ep, uint32_t* occ_wave_s, int8_t* row_s,
-                                      int& generated_size) {
+                                      int& generated_size, int staged_leader = -1, const uint32_t* staged_row = nullptr,
+                                      const uint32_t* staged_tail = nullptr, uint32_t staged_occ = 0) {
     uint64_t m = __ballot(do_reset);
     while (m) {
         const int l = __builtin_ctzll(m);
@@ -1048,7 +1060,8 @@ __device__ inline void resolve_resets(const Grp<GS>& G, const KParams& p, bool d
                 t_hs = 0;
             }
         }
-        reset_rows_wave(p, t_env, t_task, t_hs != 0, occ_wave_s ? occ_wave_s + gsel * OCC_PITCH : nullptr);
+        if (l == staged_leader) reset_rows_staged(p, t_env, staged_row, staged_tail, staged_occ);
+        else reset_rows_wave(p, t_env, t_task, t_hs != 0, occ_wave_s ? occ_wave_s + gsel * OCC_PITCH : nullptr);
     }
 }
 
@@ -1135,7 +1148,8 @@ template <int GS, int MODE, bool EXTRA>
 __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn& a, BlockShared<GS>& sh, int wave, int env,
                                  bool active, Env& e, const CellChange& ch, int task, int env_max_int, int size_new, int mi,
                                  bool need, bool changed, int8_t* grid_g, const uint32_t* occ_s, bool boost,
-                                 [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok, const TailParams& tp, int size_in) {
+                                 [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok, const TailParams& tp, int size_in,
+                                 int staged_leader, uint32_t staged_occ) {
     const StepOut o = finish_step(tp, e, env_max_int, size_new, mi);
     const bool do_reset = active && o.done && tp.autoreset;
     // the stores of an env whose episode goes on (`keep`); the counters of the wavefront
@@ -1203,8 +1217,10 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
         rv = reset_decode(rm);
         has_start = !rp.rt_enabled && rv.has_start;
     }
+    constexpr int RS = req_chunk<GS>() - 1;   // (the scratch slot start_row_prefetch staged into)
     resolve_resets<GS, EXTRA>(G, rp, do_reset, env, task, has_start, ep, nullptr,
-                              reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size);
+                              reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size, staged_leader, sh.ws[wave].hist[RS],
+                              sh.ws[wave].aux[RS], staged_occ);
     prio_at<true, 7>(boost);
     step_stores(active && !do_reset);
     if (do_reset) {
@@ -1400,6 +1416,24 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // the histogram row and the colour-index block of the changed level of every changed env start moving into LDS
     // now (LDS-DMA) and land while the physics runs
     const uint64_t chg_mask = prefetch_changes<GS, false>(G, p, sh.ws[wave], changed, env_r, task, ch);
+    // An episode that runs out in this step and restarts from a known task (pre_ok): its starting grid row and occupancy
+    // words start moving now as well -- the row by LDS-DMA into the LAST scratch slot (free unless the wavefront has as
+    // many changed envs as slots), the occupancy words into a register -- so the reset at the end of the step is stores
+    // only.  One env per wavefront (the first); any other env that resets takes reset_rows_wave.
+    int staged_leader = -1;
+    uint32_t staged_occ = aux_w;   // (any value: a dead register of the input burst)
+    if (boost) {
+        constexpr int R = req_chunk<GS>();
+        const uint64_t pm = __ballot(pre_ok && writer);
+        if (pm != 0 && __builtin_popcountll(chg_mask) < R) {
+            staged_leader = __builtin_ctzll(pm);
+            const int t_task = __builtin_amdgcn_readlane(task, staged_leader);
+            const char* row = reinterpret_cast<const char*>(p.task_start + (size_t)t_task * STRIDE) + 16 * G.lane;
+            glds16(row, sh.ws[wave].hist[R - 1]);
+            if (G.lane < CHUNKS - WAVE) glds16(row + 16 * WAVE, sh.ws[wave].aux[R - 1]);
+            if (G.lane < OCC_WORDS) staged_occ = gload(p.task_start_occ + (size_t)t_task * OCC_WORDS + G.lane);
+        }
+    }
     const TailParams tp = tail_params(kernarg_again<STEP_KERNARG_HEAD>(p));
     prio_at<true, 3>(boost);
     if (MODE == MODE_FLY) world_update<GS, MODE_FLY, true>(G, p, e, occ_s, mv, boost);
@@ -1409,10 +1443,10 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     prio_at<true, 5>(boost);
     // Everything fetched early (break colour, start byte, the DMA of the changed envs) has to be in by now; the
     // physics had the time of its sub-steps to cover it.
-    if (chg_mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (chg_mask != 0 || staged_leader >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ... and counts as consumed HERE: the counter is in order over loads and stores, so a first use at the end of
     // the step would wait for every store issued from now on (observations, histogram pieces) as well
-    asm volatile("" : "+v"(start_val), "+v"(env_max_int));
+    asm volatile("" : "+v"(start_val), "+v"(env_max_int), "+v"(staged_occ));
     // (the prefetched reset metadata too: raw words, decoded in tail_step)
     asm volatile("" : "+v"(pre.a), "+v"(pre.b), "+v"(pre.c), "+v"(pre.d));
     // The agent record is final (pose, inventory, step_no): its store is issued here -- behind that wait, so it does
@@ -1442,7 +1476,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     stamp(p, 5);
     prio_at<true, 6>(boost);
     // (KParams sits behind the preloaded head arguments: kernarg_again reads it at that offset of the kernarg segment)
-    tail_step<GS, MODE, EXTRA>(G, kernarg_again<STEP_KERNARG_HEAD>(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp, size_in);
+    tail_step<GS, MODE, EXTRA>(G, kernarg_again<STEP_KERNARG_HEAD>(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp, size_in, staged_leader, staged_occ);
 }
 
 // T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
