@@ -224,7 +224,7 @@ __device__ inline void build_level_index_wave(const int8_t* tgt_s, const int* bb
                 if (k1 == k) stage_s[32 + off + n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint8_t)p1;
                 off += n0 + __builtin_popcountll(m1);
             }
-            if (lane == 0) stage_s[16 + 14] = (uint8_t)off;
+            if (lane == 0) stage_s[16 + 14] = stage_s[16 + 15] = (uint8_t)off;   // (offs[15] = offs[14]: the empty slice change_class() clamps to)
         }
         wave_sync();
         if (lane < IGW_LEVEL_INDEX_BYTES / 16) reinterpret_cast<uint4*>(out_g + y * IGW_LEVEL_INDEX_BYTES)[lane] = st4[lane];
@@ -722,13 +722,18 @@ static_assert(IGW_TASK_INDEX_BYTES == IGW_GRID_Y * LVL_BYTES, "task colour index
 
 // class of a synthetic colour (-1: nothing can match it: 0, or outside -7..7)
 __device__ inline int colour_class(int c) { return index_class(c); }
+// ... + 1 for the histogram update, which reads offs[k - 1] and offs[k]: 0 = no class; a colour outside -7..7 (block ids
+// are sanitised where tasks and states enter: cannot happen) clamps to 0 / 15, and offs[15] = offs[14] is an empty slice
+__device__ inline uint32_t change_class(int c) {
+    const int k = min(max(c + 7 + (int)((uint32_t)c >> 31), 0), 15);   // (one v_med3_i32)
+    return c == 0 ? 0u : (uint32_t)k;
+}
 
 template <int R>
 struct WaveScratch {
     alignas(16) uint32_t hist[R][HIST_ROW / 2];
     alignas(16) uint32_t aux[R][LVL_WORDS];  // the colour-index block of each staged env's changed level
-    alignas(8) uint32_t chg[WAVE / R][2];    // the wave's changed envs in lane order: {env, level | x | z | old | new}
-    uint32_t res[WAVE / R];                  // ... and their new histogram maxima
+    alignas(8) uint32_t chg[WAVE / R][2];    // the wave's changed envs in lane order: {env, x | z << 4 | (old class + 1) << 8 | (new class + 1) << 12}
 };
 
 template <int GS>
@@ -948,42 +953,44 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
     const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     const int rank = below - ((G.gl > 0 && grp_changed) ? 1 : 0);
     if (grp_changed && G.gl == 0) {
-        int a = old_colour(ch) - start_val, b = ch.new_val - start_val;  // old / new synthetic colour, a != b
-        a = (a < -7 || a > 7) ? 0 : a;
-        b = (b < -7 || b > 7) ? 0 : b;
+        // old / new synthetic colour (a != b) as its class + 1 -- 0: nothing in a target can match it
+        const int a = old_colour(ch) - start_val, b = ch.new_val - start_val;
         *reinterpret_cast<uint2*>(ws.chg[rank]) =
-            make_uint2((uint32_t)env, (uint32_t)ch.xz | ((uint32_t)(a & 15) << 8) | ((uint32_t)(b & 15) << 12));
+            make_uint2((uint32_t)env, (uint32_t)ch.xz | (change_class(a) << 8) | (change_class(b) << 12));
     }
     const int slot = lane >> 4, sub = lane & 15, mi = sub >> 2, q = lane & 3;
     uint64_t m = mask;
+    int result = 0;
     for (int base = 0; base < E; base += R) {
         if (base > 0 && IGW_DIAG_FLAG(p, 256)) break;  // diag 256: what the later passes of a wave with more than R changes cost
         const int cnt = min(R, E - base);
+        if (base > 0) {   // more changed envs than scratch rows: the later chunks are fetched only now (rare)
+            if (base == R) {   // (the first chunk's leaders: their DMA was the caller's)
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-            if (k < cnt) {
-                const int l = next_leader(m);
-                // more changed envs than scratch rows: the later chunks are fetched only now (rare)
-                if (base > 0)
+                for (int k = 0; k < R; k++) m &= m - 1;
+            }
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                if (k < cnt) {
+                    const int l = next_leader(m);
                     dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
                                              __builtin_amdgcn_readlane(ch.lvl, l));
+                }
             }
+            // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks wait here
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks wait here
-        if (base > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         const bool my = slot < cnt;
         const int sl = my ? slot : 0;
         const uint2 ent = my ? *reinterpret_cast<const uint2*>(ws.chg[base + sl]) : make_uint2(0u, 0u);
         const uint8_t* blk = reinterpret_cast<const uint8_t*>(ws.aux[sl]);
         const int gx = (int)(ent.y & 15u), gz = (int)((ent.y >> 4) & 15u);
-        const int a = ((int)(ent.y << 20)) >> 28, b = ((int)(ent.y << 16)) >> 28;  // sign-extended 4-bit fields
-        const int ca = colour_class(a), cb = colour_class(b);
-        // the two colour classes' slices of the level's cell list
-        int oa0 = 0, oa1 = 0, ob0 = 0, ob1 = 0;
-        if (my && ca >= 0) { oa0 = blk[LVL_OFFS + ca]; oa1 = blk[LVL_OFFS + ca + 1]; }
-        if (my && cb >= 0) { ob0 = blk[LVL_OFFS + cb]; ob1 = blk[LVL_OFFS + cb + 1]; }
-        const int na = oa1 - oa0, n = na + (ob1 - ob0);
+        const int ka = (int)((ent.y >> 8) & 15u), kb = (int)((ent.y >> 12) & 15u);
+        // the two colour classes' slices of the level's cell list (class + 1 == 0: an empty slice.  The reads are
+        // unconditional -- a lane without an env reads slot 0's block -- and the select comes after them: no branch)
+        const int oa0 = blk[LVL_OFFS - 1 + ka], oa1 = blk[LVL_OFFS + ka], ob0 = blk[LVL_OFFS - 1 + kb], ob1 = blk[LVL_OFFS + kb];
+        const int na = (my && ka != 0) ? oa1 - oa0 : 0, n = na + ((my && kb != 0) ? ob1 - ob0 : 0);
         // rotation q's bounding box: admissible translations dx in [xmax - 10, xmin], dz in [zmax - 10, zmin] (task.py:62-72)
         const int bb = my ? (int)reinterpret_cast<const uint32_t*>(blk)[q] : 0;
         const int xmin = (int)(int8_t)(bb & 0xff), dxlo = (int)(int8_t)((bb >> 8) & 0xff) - 10;
@@ -1004,8 +1011,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 const int u = rx - gx - dxlo, v = rz - gz - dzlo;
                 if ((unsigned)u <= (unsigned)(xmin - dxlo) && (unsigned)v <= (unsigned)(zmin - dzlo)) {  // (extents <= 10: both bounds >= 0)
                     const int bin = q * 121 + __mul24(u, 11) + v;
-                    const uint32_t one = 1u << (16 * (bin & 1));
-                    atomicAdd(&ws.hist[sl][bin >> 1], dec ? 0u - one : one);
+                    atomicAdd(&ws.hist[sl][bin >> 1], (dec ? 0xffffffffu : 1u) << (16 * (bin & 1)));   // -/+ 1 in the bin's half
                 }
             }
         }
@@ -1026,13 +1032,16 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                     __builtin_elementwise_max(__builtin_bit_cast(us2, now.z), __builtin_bit_cast(us2, now.w))));
             }
         }
+        // ... valid in lane 15 of the slot's sixteen lanes: the env's lanes fetch it from there (a cross-lane read
+        // through the LDS crossbar: no LDS write / barrier / read)
         const int best = row_max_nonneg((int)max((uint32_t)pm.x, (uint32_t)pm.y));
-        if (my && sub == 15) ws.res[base + sl] = (uint32_t)best;
+        const int mine = __builtin_amdgcn_ds_bpermute((((rank - base) & (R - 1)) * 16 + 15) * 4, best);
+        if (grp_changed && rank >= base && rank < base + R) result = mine;
     }
     // a fused rollout reads the rows again in its next step: let the stores reach L2 first
     if (L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
-    return grp_changed ? (int)ws.res[rank] : 0;
+    return result;
 }
 
 // auto-reset rows of every done env of this wave (whole wave per env, coalesced).  With the RandomTasks
@@ -1264,7 +1273,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     const Grp<GS> G;
     TrigCtx trig;
     trig.lut = trig_lut();
-    const int wave = threadIdx.x / WAVE;
+    // (wave-uniform, and the compiler is told so: the addresses of the wavefront's LDS scratch are scalar arithmetic)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const int slot = threadIdx.x / GS;
     const int env = blockIdx.x * BlockShared<GS>::EPB + slot;
     const int wave_env0 = blockIdx.x * BlockShared<GS>::EPB + wave * BlockShared<GS>::EPW;

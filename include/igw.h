@@ -63,7 +63,8 @@ extern "C" {
  * IGW_LEVEL_INDEX_BYTES block:
  *    0 i8 bbox[4][4]   per rotation xmin, xmax, zmin, zmax of the synthetic target (copy of the metadata's)
  *   16 u8 offs[15]     start of each colour class in cells[]; class = colour + 7 for -7..-1, colour + 6 for 1..7
- *                      (synthetic colours = target - start with block ids 0..7); offs[14] = cells on this level
+ *                      (synthetic colours = target - start with block ids 0..7); offs[14] = cells on this level;
+ *                      byte 31 repeats offs[14] (an empty slice behind the last class)
  *   32 u8 cells[<=121] (x+5) << 4 | (z+5) of the level's target cells, sorted by colour class
  * written by igw_prepare_tasks and by the on-device RandomTasks generator */
 #define IGW_LEVEL_INDEX_BYTES 160

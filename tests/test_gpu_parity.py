@@ -250,7 +250,7 @@ def _expected_index(target_syn, bbox16):
             for c in np.nonzero(lvl == colour)[0]:
                 out[y, 32 + pos] = (c // 11) << 4 | (c % 11)
                 pos += 1
-        out[y, 16 + 14] = pos
+        out[y, 16 + 14] = out[y, 16 + 15] = pos   # (offs[15] repeats offs[14], present only where the level has cells)
     return out.reshape(-1)
 
 

@@ -99,6 +99,15 @@ for k in range(8):
     m = young[None, :] & (n_ch == k) & (n_rt == 0)
     if m.sum() > 5:
         print(f'    {k} changes: n {int(m.sum()):6d}  lifetime {life[m].mean():7.0f}  histogram phase {d[:, :, 4][m].mean():6.0f}  physics {d[:, :, 2][m].mean():6.0f}')
+# the launch ends with its LAST wave: what the span would be without each class of wave (the tail's attribution)
+end = t[:, :, 6] - t[:, :, 0].min(1, keepdims=True)
+print(f'  launch span (first start -> last end): mean {end.max(1).mean():.0f}; the same without the waves that have')
+for label, m in (('5+ changes', n_ch >= 5), ('3+ changes', n_ch >= 3), ('a reset', n_rt > 0), ('a break', n_brk > 0),
+                 ('sub-steps 4+', max_m >= 4), ('any change', n_ch >= 1)):
+    e2 = np.where(m, 0, end)
+    print(f'    {label:14s} (share {m.mean():.4f}): {e2.max(1).mean():.0f}')
+srt = np.sort(end, axis=1)
+print('  end time of the k-th last wave, mean over launches: ' + '  '.join(f'k={k}: {srt[:, -k].mean():.0f}' for k in (1, 2, 4, 8, 16, 41, 205, 2048)))
 # which waves end last
 last = life.argmax(1)
 print('  slowest wave per launch: changes', n_ch[np.arange(len(last)), last].tolist())
