@@ -887,17 +887,21 @@ __device__ inline void glds16_sc1(const void*, uint32_t*) {}
 // The LDS-DMA loads of one changed env into scratch slot k (whole wave): its histogram row and the colour-index
 // block of the changed cell's level.  L2: bypass this CU's L1 (the fused rollout re-reads rows it stored earlier in
 // the same launch, and may have regenerated the task row).
-template <int R, bool L2>
-__device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, int k, int env, int task, int level) {
+template <bool L2>
+__device__ inline void dma_change_rows(const KParams& p, uint32_t* hist_dst, uint32_t* aux_dst, int env, int task, int level) {
     const int lane = __lane_id();
     const char* hrow = reinterpret_cast<const char*>(p.hist + (size_t)env * HIST_ROW) + 16 * lane;
-    if (L2) glds16_sc1(hrow, ws.hist[k]);  // cache policy sc1
-    else glds16(hrow, ws.hist[k]);
+    if (L2) glds16_sc1(hrow, hist_dst);  // cache policy sc1
+    else glds16(hrow, hist_dst);
     const uint8_t* blk = p.task_index + (size_t)task * IGW_TASK_INDEX_BYTES + level * LVL_BYTES + 16 * lane;
     if (lane < LVL_BYTES / 16) {
-        if (L2) glds16_sc1(blk, ws.aux[k]);
-        else glds16(blk, ws.aux[k]);
+        if (L2) glds16_sc1(blk, aux_dst);
+        else glds16(blk, aux_dst);
     }
+}
+template <int R, bool L2>
+__device__ inline void dma_change_inputs(const KParams& p, WaveScratch<R>& ws, int k, int env, int task, int level) {
+    dma_change_rows<L2>(p, ws.hist[k], ws.aux[k], env, task, level);
 }
 
 // The wave's changed envs are named by their leader lanes (a ballot); for the DMA their parameters travel as
@@ -941,13 +945,29 @@ __device__ inline int row_max_nonneg(int v) {
 // and within the sixteen lanes of a slot match slot = (lane / 4) % 4, rotation = lane % 4.
 template <int GS, bool L2>
 __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveScratch<req_chunk<GS>()>& ws,
-                                      uint64_t mask, int env, int task, const CellChange& ch, int start_val) {
+                                      uint64_t mask, int env, int task, const CellChange& ch, int start_val,
+                                      uint32_t* spare = nullptr) {
     constexpr int R = req_chunk<GS>();
     if (mask == 0) return 0;
     // (the fused rollout arrives with its loads in flight: the break's colour, the start byte, the DMA)
     if (L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int lane = __lane_id();
     const int E = __builtin_popcountll(mask);
+    // More changed envs than scratch rows (one wavefront in 150 to 400): the rows of the FIRST env of the second chunk
+    // start moving now, into `spare` -- LDS the caller no longer needs (the step kernel: the wavefront's occupancy
+    // rows, dead once the physics is done) -- and land while the first chunk is worked on.  Without it the second
+    // chunk's memory round trip starts only when the first chunk's rows are free again, and such a wavefront is the
+    // last one of the launch more often than not.
+    uint64_t m = mask;
+    if (E > R) {
+#pragma unroll
+        for (int k = 0; k < R; k++) m &= m - 1;   // (the first chunk's leaders: their DMA was the caller's)
+        if (spare != nullptr) {
+            const int l = __builtin_ctzll(m);
+            dma_change_rows<L2>(p, spare, spare + HIST_ROW / 2, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
+                                __builtin_amdgcn_readlane(ch.lvl, l));
+        }
+    }
     // this lane's env among the changed envs of the wave: leaders below it (its own leader's bit excluded)
     const bool grp_changed = (mask >> (lane & ~(GS - 1))) & 1ull;
     const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -959,32 +979,24 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
             make_uint2((uint32_t)env, (uint32_t)ch.xz | (change_class(a) << 8) | (change_class(b) << 12));
     }
     const int slot = lane >> 4, sub = lane & 15, mi = sub >> 2, q = lane & 3;
-    uint64_t m = mask;
     int result = 0;
-    for (int base = 0; base < E; base += R) {
-        if (base > 0 && IGW_DIAG_FLAG(p, 256)) break;  // diag 256: what the later passes of a wave with more than R changes cost
+    // One pass over up to R changed envs, lane-parallel (see the section comment): env slot = lane / 16, and within the
+    // sixteen lanes of a slot match slot = (lane / 4) % 4, rotation = lane % 4.  `later`: a pass after the first, whose
+    // slot 0 may be the spare rows.
+    const auto pass = [&](int base, auto later) {
         const int cnt = min(R, E - base);
-        if (base > 0) {   // more changed envs than scratch rows: the later chunks are fetched only now (rare)
-            if (base == R) {   // (the first chunk's leaders: their DMA was the caller's)
-#pragma unroll
-                for (int k = 0; k < R; k++) m &= m - 1;
-            }
-#pragma unroll
-            for (int k = 0; k < R; k++) {
-                if (k < cnt) {
-                    const int l = next_leader(m);
-                    dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
-                                             __builtin_amdgcn_readlane(ch.lvl, l));
-                }
-            }
-            // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks wait here
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         wave_sync();
         const bool my = slot < cnt;
         const int sl = my ? slot : 0;
         const uint2 ent = my ? *reinterpret_cast<const uint2*>(ws.chg[base + sl]) : make_uint2(0u, 0u);
+        uint32_t* hrow = ws.hist[sl];
         const uint8_t* blk = reinterpret_cast<const uint8_t*>(ws.aux[sl]);
+        if constexpr (decltype(later)::value) {
+            if (base == R && spare != nullptr && sl == 0) {
+                hrow = spare;
+                blk = reinterpret_cast<const uint8_t*>(spare + HIST_ROW / 2);
+            }
+        }
         const int gx = (int)(ent.y & 15u), gz = (int)((ent.y >> 4) & 15u);
         const int ka = (int)((ent.y >> 8) & 15u), kb = (int)((ent.y >> 12) & 15u);
         // the two colour classes' slices of the level's cell list (class + 1 == 0: an empty slice.  The reads are
@@ -1011,7 +1023,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
                 const int u = rx - gx - dxlo, v = rz - gz - dzlo;
                 if ((unsigned)u <= (unsigned)(xmin - dxlo) && (unsigned)v <= (unsigned)(zmin - dzlo)) {  // (extents <= 10: both bounds >= 0)
                     const int bin = q * 121 + __mul24(u, 11) + v;
-                    atomicAdd(&ws.hist[sl][bin >> 1], (dec ? 0xffffffffu : 1u) << (16 * (bin & 1)));   // -/+ 1 in the bin's half
+                    atomicAdd(&hrow[bin >> 1], (dec ? 0xffffffffu : 1u) << (16 * (bin & 1)));   // -/+ 1 in the bin's half
                 }
             }
         }
@@ -1021,7 +1033,7 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         us2 pm = {0, 0};
         if (my) {
-            const uint4* row = reinterpret_cast<const uint4*>(ws.hist[sl]);
+            const uint4* row = reinterpret_cast<const uint4*>(hrow);
             uint4* dst = reinterpret_cast<uint4*>(p.hist + (size_t)ent.x * HIST_ROW);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1037,6 +1049,23 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         const int best = row_max_nonneg((int)max((uint32_t)pm.x, (uint32_t)pm.y));
         const int mine = __builtin_amdgcn_ds_bpermute((((rank - base) & (R - 1)) * 16 + 15) * 4, best);
         if (grp_changed && rank >= base && rank < base + R) result = mine;
+    };
+    pass(0, std::false_type{});
+    for (int base = R; base < E; base += R) {   // (rare) the later chunks are fetched only now
+        if (IGW_DIAG_FLAG(p, 256)) break;  // diag 256: what the later passes of a wave with more than R changes cost
+        const int cnt = min(R, E - base);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            if (k < cnt) {
+                const int l = next_leader(m);
+                if (!(k == 0 && base == R && spare != nullptr))   // (already on its way)
+                    dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
+                                             __builtin_amdgcn_readlane(ch.lvl, l));
+            }
+        }
+        // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks wait here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pass(base, std::true_type{});
     }
     // a fused rollout reads the rows again in its next step: let the stores reach L2 first
     if (L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1471,7 +1500,7 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
         env_store(e, p.agent + env);
     }
     stamp(p, 4);
-    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch, start_val);
+    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch, start_val, occ_wave_s);
     const int size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
     const bool need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
     int mi = e.max_int;
