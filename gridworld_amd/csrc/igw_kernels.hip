@@ -582,7 +582,15 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
     // build_zone (their outcome is known: inside) and the selects behind them.
     bool inside = false;
     if constexpr (!FLY) inside = __all((__builtin_fabs(e.x) < 6.0) & (__builtin_fabs(e.z) < 6.0) & (e.y >= -0.5) & (e.y < 9.0));
-    for (int i = 0; i < (IGW_DIAG_FLAG(p, 4) ? 0 : m); i++) {  // _update, :222-262
+    bool owned = false;
+    if constexpr (!FLY && GS >= 4) {
+        if (inside && !IGW_DIAG_FLAG(p, 4)) {   // (wave-uniform) the common case: see walk_substeps_owned
+            vy_pre = walk_substeps_owned<GS>(G, e, occ_s, mv.x, mv.y, mv.z, m, dt);
+            prio_at<PRIO, 4>(boost);
+            owned = true;
+        }
+    }
+    for (int i = 0; i < ((IGW_DIAG_FLAG(p, 4) || owned) ? 0 : m); i++) {  // _update, :222-262
         if (i == 1) prio_at<PRIO, 4>(boost);
         const double speed = FLY ? FLYING_SPEED : WALKING_SPEED;
         const double d = dt * speed;
