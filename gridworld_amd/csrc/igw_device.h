@@ -607,31 +607,42 @@ __device__ inline void collide_split(const Grp<GS>& G, Env& e, const uint32_t* o
     e.vy = dpp_quad<QUAD_BCAST0>(vy);
 }
 
-// The sub-steps of a walker whose whole wavefront stays inside the padded zone (world_update), axis-owned: lane
-// (gl & 3) = 1 / 2 / 0, 3 of a group carries ONLY the x / z / y coordinate through all the sub-steps of the step -- its
-// own displacement, its own candidate position, its own collision face (collide_split's arithmetic, unchanged) -- and
-// the lanes exchange just the rounded cell coordinates (three one-dword broadcasts per sub-step) for the probe index.
+// The sub-steps of a step (world_update) for groups of four or more lanes, axis-owned: lane (gl & 3) = 1 / 2 / 0, 3 of a
+// group carries ONLY the x / z / y coordinate through all the sub-steps -- its own displacement, its own candidate
+// position, its own collision face (collide_split's arithmetic, unchanged) -- and the lanes exchange just the rounded
+// cell coordinates (three one-dword broadcasts per sub-step) for the probe index, plus, when the wavefront is not known
+// to stay inside the padded zone (!INSIDE: flying always; walkers near the border), one bit per axis for the zone test.
 // collide_split handed every lane all three positions after every sub-step: six broadcast dwords, three candidate
 // positions and three roundings per lane, and the selects that pick the lane's own out of them again.
 // The x / z lanes run the y lanes' velocity code on a neutral element: their "velocity" is -0.0 and their "gravity"
 // +0.0, so vy stays -0.0 (-0.0 - 0.0, max(-0.0, -50)), vy * dt is -0.0, and displacement + -0.0 is the displacement
 // bit for bit (x + -0.0 == x for every x, -0.0 included: no select needed to keep the axes apart).
 // Returns vy as it was before the last sub-step's clamp (time_int_steps, core/world.py:243-250).
-template <int GS>
-__device__ inline double walk_substeps_owned(const Grp<GS>& G, Env& e, const uint32_t* occ_s, double mvx, double mvy, double mvz, int m, double dt) {
+template <int GS, bool FLY, bool INSIDE>
+__device__ inline double substeps_owned(const Grp<GS>& G, Env& e, const uint32_t* occ_s, double mvx, double mvy, double mvz,
+                                        int m, double dt) {
     static_assert(GS >= 4, "needs three lanes per env");
     const int a = G.gl & 3;
     const bool ax = a == 1, az = a == 2, ay = !(ax || az);
     const int ux = ax ? 1 : 0, uz = az ? 1 : 0, uy = ay ? 1 : 0;
     double pa = ax ? e.x : az ? e.z : e.y;
-    const double ca = (ax ? mvx : az ? mvz : mvy) * (dt * WALKING_SPEED);   // ddx / ddz / the motion part of ddy
+    const double ca = (ax ? mvx : az ? mvz : mvy) * (dt * (FLY ? FLYING_SPEED : WALKING_SPEED));   // ddx / ddz / the motion part of ddy
     const double ga = ay ? dt * GRAVITY : 0.0;
     double vy = ay ? e.vy : -0.0, vy_pre = 0.0;
     for (int i = 0; i < m; i++) {  // _update, core/world.py:222-262
-        vy -= ga;
-        vy_pre = vy;
-        vy = vy > -TERMINAL_VELOCITY ? vy : -TERMINAL_VELOCITY;
-        const double c = pa + (ca + vy * dt);
+        if constexpr (!FLY) {
+            vy -= ga;
+            vy_pre = vy;
+            vy = vy > -TERMINAL_VELOCITY ? vy : -TERMINAL_VELOCITY;
+        }
+        double c = pa + (ca + vy * dt);
+        bool moves = true;   // flying outside the padded zone: the sub-step does nothing at all
+        if constexpr (!INSIDE) {   // build_zone(candidate, pad = 2), one comparison pair per axis lane
+            const int ok = ay ? (int)((-3.0 <= c) & (c < 10.0)) : (int)(__builtin_fabs(c) <= 7.0);
+            const bool zone = (dpp_quad<QUAD_BCAST0>(ok) & dpp_quad<QUAD_BCAST1>(ok) & dpp_quad<QUAD_BCAST2>(ok)) != 0;
+            if constexpr (FLY) moves = zone;
+            else c = (zone || ay) ? c : pa;   // outside it a walker only moves vertically
+        }
         const int n = rint_i32(c);
         const int ny = dpp_quad<QUAD_BCAST0>(n), nx = dpp_quad<QUAD_BCAST1>(n), nz = dpp_quad<QUAD_BCAST2>(n);
         // (from here on: collide_split, with this lane's axis only)
@@ -645,8 +656,9 @@ __device__ inline double walk_substeps_owned(const Grp<GS>& G, Env& e, const uin
         const bool b1 = (int)occ_test(occ_s, ya0 + xa + za) | (int)occ_test(occ_s, ya1 + xa + za);
         const double d = sgn * f1;
         const bool h1 = !(d < PAD) && b1;
-        pa = h1 ? c - (d - PAD) * f1 : c;
-        if (uy && h1) vy = 0.0;
+        const double r = h1 ? c - (d - PAD) * f1 : c;
+        pa = moves ? r : pa;
+        if (uy && h1 && moves) vy = 0.0;
     }
     e.y = dpp_quad<QUAD_BCAST0>(pa);
     e.x = dpp_quad<QUAD_BCAST1>(pa);

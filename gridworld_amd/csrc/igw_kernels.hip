@@ -583,9 +583,10 @@ __device__ inline void world_update(const Grp<GS>& G, const KParams& p, Env& e, 
     bool inside = false;
     if constexpr (!FLY) inside = __all((__builtin_fabs(e.x) < 6.0) & (__builtin_fabs(e.z) < 6.0) & (e.y >= -0.5) & (e.y < 9.0));
     bool owned = false;
-    if constexpr (!FLY && GS >= 4) {
-        if (inside && !IGW_DIAG_FLAG(p, 4)) {   // (wave-uniform) the common case: see walk_substeps_owned
-            vy_pre = walk_substeps_owned<GS>(G, e, occ_s, mv.x, mv.y, mv.z, m, dt);
+    if constexpr (GS >= 4) {
+        if (!IGW_DIAG_FLAG(p, 4)) {   // groups of four or more lanes: see substeps_owned
+            if (!FLY && inside) vy_pre = substeps_owned<GS, FLY, true>(G, e, occ_s, mv.x, mv.y, mv.z, m, dt);   // (wave-uniform)
+            else vy_pre = substeps_owned<GS, FLY, false>(G, e, occ_s, mv.x, mv.y, mv.z, m, dt);
             prio_at<PRIO, 4>(boost);
             owned = true;
         }
