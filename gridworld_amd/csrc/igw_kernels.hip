@@ -1449,6 +1449,12 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
         if (bad && writer) stat_add(p.stats, IGW_STAT_BAD_ACTION, 1);
         ap = world_act_pre<GS, MODE_FLY>(G, p, e, trig, f[0], f[1], f[2], inventory, f[3], f[4], placement == 2, placement == 1, mv);
     }
+#ifdef IGW_DIAG
+    if (IGW_DIAG_FLAG(p, 512)) {   // diag 512: input burst + action parse + world_act_pre, nothing else (results kept alive)
+        asm volatile("" :: "v"(mv.x), "v"(mv.z), "v"(mv.y), "v"(ap.vx), "v"(ap.vy), "v"(ap.vz), "v"(e.yaw), "v"(e.pitch), "v"(e.vy), "v"(e.active));
+        return;
+    }
+#endif
     // hit_test (core/world.py:73-99) for the envs that place or break -- 8 of the 18 walking actions.
     Hit h;
     h.hit = false; h.have_prev = false;

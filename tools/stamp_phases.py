@@ -69,11 +69,9 @@ t = a[:, :, :7].astype(np.float64)
 feat = a[:, :, 7]
 n_ch, n_rs, n_rt, max_m, n_brk = feat & 0xff, (feat >> 8) & 0xff, (feat >> 16) & 0xff, (feat >> 24) & 0xff, (feat >> 32) & 0xff
 life = t[:, :, 6] - t[:, :, 0]
-span = t[:, :, 6].max(1) - t[:, :, 0].min(1)
 names = ['loads', 'action + hit_test', 'physics', 'world_step tail', 'histogram update', 'rescan/finish/stores']
 d = np.diff(t, axis=2)
 print(f'lanes/env {gs}: {waves} waves, {a.shape[0]} launches; shader cycles; debug flags {flags}')
-print(f'  first start -> last end: mean {span.mean():.0f}   start spread {np.mean(t[:, :, 0].max(1) - t[:, :, 0].min(1)):.0f}')
 print(f'  wave lifetime: mean {life.mean():.0f} p50 {np.percentile(life, 50):.0f} p90 {np.percentile(life, 90):.0f} '
       f'p99 {np.percentile(life, 99):.0f} max(mean over launches) {life.max(1).mean():.0f}')
 for i, nm in enumerate(names):
@@ -99,15 +97,29 @@ for k in range(8):
     m = young[None, :] & (n_ch == k) & (n_rt == 0)
     if m.sum() > 5:
         print(f'    {k} changes: n {int(m.sum()):6d}  lifetime {life[m].mean():7.0f}  histogram phase {d[:, :, 4][m].mean():6.0f}  physics {d[:, :, 2][m].mean():6.0f}')
-# the launch ends with its LAST wave: what the span would be without each class of wave (the tail's attribution)
-end = t[:, :, 6] - t[:, :, 0].min(1, keepdims=True)
-print(f'  launch span (first start -> last end): mean {end.max(1).mean():.0f}; the same without the waves that have')
-for label, m in (('5+ changes', n_ch >= 5), ('3+ changes', n_ch >= 3), ('a reset', n_rt > 0), ('a break', n_brk > 0),
-                 ('sub-steps 4+', max_m >= 4), ('any change', n_ch >= 1)):
-    e2 = np.where(m, 0, end)
-    print(f'    {label:14s} (share {m.mean():.4f}): {e2.max(1).mean():.0f}')
-srt = np.sort(end, axis=1)
-print('  end time of the k-th last wave, mean over launches: ' + '  '.join(f'k={k}: {srt[:, -k].mean():.0f}' for k in (1, 2, 4, 8, 16, 41, 205, 2048)))
+# The launch ends with its LAST wave.  s_memtime counts per CU (the counters of different CUs are tens of millions of
+# cycles apart), so wave times are comparable only within a CU: block b of the 65,536-env launch runs on CU b % 256
+# (blocks b, b + 256, b + 512, b + 768 share a clock), and every time below is relative to the first start on the CU.
+if waves == 4096:
+    tc = t.reshape(t.shape[0], 4, 256, 4, 7)   # [launch, dispatch round, CU, wave of the block, stamp]
+    t0 = tc[..., 0].min(axis=(1, 3), keepdims=True)
+    end = (tc[..., 6] - t0).reshape(t.shape[0], waves)
+    start = (tc[..., 0] - t0).reshape(t.shape[0], waves)
+    cu_span = end.reshape(t.shape[0], 4, 256, 4).max(axis=(1, 3))
+    print(f'  per-CU span (first start -> last end on the CU): mean {cu_span.mean():.0f}  slowest CU of a launch {cu_span.max(1).mean():.0f}'
+          f'  (the launch waits for that one); start spread within a CU {start.max(1).mean():.0f}')
+    print('  the slowest CU\'s span if the waves with ... did not exist:')
+    for label, msk in (('5+ changes', n_ch >= 5), ('3+ changes', n_ch >= 3), ('a reset', n_rt > 0), ('a break', n_brk > 0),
+                       ('sub-steps 4+', max_m >= 4), ('any change', n_ch >= 1),
+                       ('the last dispatch round', np.broadcast_to((np.arange(waves) // 4) >= 768, n_ch.shape))):
+        print(f'    {label:24s} (share {msk.mean():.4f}): {np.where(msk, 0, end).max(1).mean():.0f}')
+    srt = np.sort(end, axis=1)
+    print('  end of the k-th last wave, mean over launches: ' + '  '.join(f'k={k}: {srt[:, -k].mean():.0f}' for k in (1, 2, 4, 8, 16, 41, 205, 2048)))
+    top = np.argsort(end, axis=1)[:, -16:]
+    print('  phases of the 16 last waves: ' + '  '.join(f'{nm.split()[0]} {np.take_along_axis(d[:, :, i], top, 1).mean():.0f}' for i, nm in enumerate(names)))
+    for k in range(4):
+        msk = (np.arange(waves) // 4) // 256 == k
+        print(f'    dispatch round {k}: start {start[:, msk].mean():5.0f}  end {end[:, msk].mean():6.0f}')
 # which waves end last
 last = life.argmax(1)
 print('  slowest wave per launch: changes', n_ch[np.arange(len(last)), last].tolist())
