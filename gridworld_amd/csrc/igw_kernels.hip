@@ -1059,21 +1059,25 @@ __device__ inline int resolve_changes(const Grp<GS>& G, const KParams& p, WaveSc
         const int mine = __builtin_amdgcn_ds_bpermute((((rank - base) & (R - 1)) * 16 + 15) * 4, best);
         if (grp_changed && rank >= base && rank < base + R) result = mine;
     };
-    pass(0, std::false_type{});
-    for (int base = R; base < E; base += R) {   // (rare) the later chunks are fetched only now
-        if (IGW_DIAG_FLAG(p, 256)) break;  // diag 256: what the later passes of a wave with more than R changes cost
-        const int cnt = min(R, E - base);
+    // (the step kernel gets the first pass peeled: its common path carries none of the later chunks' bookkeeping.  The
+    // fused rollout keeps ONE copy of the pass in one loop: two copies cost it three registers more than its launch bound has)
+    if constexpr (!L2) pass(0, std::false_type{});
+    for (int base = L2 ? 0 : R; base < E; base += R) {   // (rare beyond the first) the later chunks are fetched only now
+        if (!L2 || base > 0) {
+            if (IGW_DIAG_FLAG(p, 256)) break;  // diag 256: what the later passes of a wave with more than R changes cost
+            const int cnt = min(R, E - base);
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-            if (k < cnt) {
-                const int l = next_leader(m);
-                if (!(k == 0 && base == R && spare != nullptr))   // (already on its way)
-                    dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
-                                             __builtin_amdgcn_readlane(ch.lvl, l));
+            for (int k = 0; k < R; k++) {
+                if (k < cnt) {
+                    const int l = next_leader(m);
+                    if (!(k == 0 && base == R && spare != nullptr))   // (already on its way)
+                        dma_change_inputs<R, L2>(p, ws, k, __builtin_amdgcn_readlane(env, l), __builtin_amdgcn_readlane(task, l),
+                                                 __builtin_amdgcn_readlane(ch.lvl, l));
+                }
             }
+            // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks wait here
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // the first chunk's DMA was waited for by the caller (before it issued its output stores); later chunks wait here
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pass(base, std::true_type{});
     }
     // a fused rollout reads the rows again in its next step: let the stores reach L2 first
