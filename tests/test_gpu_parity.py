@@ -348,6 +348,43 @@ def test_start_grids_incremental_reward_vs_oracle(gs):
     _check_occ(env)
 
 
+@pytest.mark.parametrize('gs', [4, 8, 64, 1])
+def test_autoreset_restores_starting_grids_desynchronised(gs):
+    """Auto-reset at max_steps with partial STARTING grids (CDM structures), episodes de-synchronised by masked resets
+    in the first steps: a wavefront then has one env whose episode runs out (its starting row is staged during the step),
+    several (the first staged, the others restored at the end), or one in a step where many of its envs changed a block
+    (no scratch slot left to stage into).  Oracle at every step; histogram and occupancy recounted at the end."""
+    from gridworld_amd import VecGridWorld
+    from oracle import oracle as O
+    fx = GR.load_fixture('s2_walk_cdm')
+    reps = 41
+    tg = np.tile(fx['targets'], (reps, 1, 1, 1))[:333]
+    st = np.tile(fx['starts'], (reps, 1, 1, 1))[:333]
+    n, T = len(tg), 70
+    kw = dict(size_reward=False, max_steps=9)
+    env = VecGridWorld(n, autoreset=True, lanes_per_env=gs, **kw)
+    env.set_tasks(tg, st)
+    env.reset()
+    ob = O.OracleBatch(n, **kw)
+    ob.set_tasks(tg, st)
+    ob.reset()
+    rng = np.random.RandomState(4)
+    acts = rng.choice([1, 3, 5, 7, 9, 12, 14, 14, 15, 16, 16, 16, 17, 17, 17], size=(T, n)).astype(np.int32)
+    acts[40:44] = np.array([14, 14, 17, 16], np.int32)[:, None]   # every env looks down, places, breaks: all change at once
+    idx = np.arange(n)
+    for t in range(T):
+        if t < 8:   # shifts the episode phase of one env in eight
+            m = (idx % 8 == t).astype(np.uint8)
+            env.reset(mask=torch.as_tensor(m))
+            ob.reset(mask=m)
+        env.step(torch.as_tensor(acts[t]))
+        ob.step_walking(acts[t], autoreset=True, nthreads=8)
+        _compare(env, ob, f'step {t}')
+    assert env.stats()['resets'] >= n * (T // 9 - 1)
+    _check_hist(env, tg, st, sample=range(0, n, 4))
+    _check_occ(env)
+
+
 @pytest.mark.parametrize('gs', [0, 16, 1])
 def test_single_colour_floors_vs_oracle(gs):
     """Targets whose levels are full floors of one colour: one placed block matches up to 121 target cells at once
