@@ -346,7 +346,7 @@ __device__ inline void reset_rows_wave(const KParams& p, int env, int task, bool
     gstore(dh + lane, zero);
 }
 
-// The same for the ONE env per wavefront whose starting row the step fetched ahead (start_row_prefetch): the grid row is
+// The same for the ONE env per wavefront whose starting row the step fetched ahead (step_kernel, "staged"): the grid row is
 // in LDS, the occupancy words in a register of lanes 0..47 -- stores only, no memory round trip at the end of the step.
 __device__ inline void reset_rows_staged(const KParams& p, int env, const uint32_t* row_s, const uint32_t* tail_s, uint32_t occ_w) {
     const int lane = __lane_id();
@@ -1268,7 +1268,7 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
         rv = reset_decode(rm);
         has_start = !rp.rt_enabled && rv.has_start;
     }
-    constexpr int RS = req_chunk<GS>() - 1;   // (the scratch slot start_row_prefetch staged into)
+    constexpr int RS = req_chunk<GS>() - 1;   // (the scratch slot the step kernel staged the starting row into)
     resolve_resets<GS, EXTRA>(G, rp, do_reset, env, task, has_start, ep, nullptr,
                               reinterpret_cast<int8_t*>(&sh.ws[wave]), generated_size, staged_leader, sh.ws[wave].hist[RS],
                               sh.ws[wave].aux[RS], staged_occ);
