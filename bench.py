@@ -130,9 +130,9 @@ def self_launch(args):
                 sys.stderr.write(line)
         rc = proc.wait()
         if got:
-            if rc != 0:   # the result is out; a rank that aborted while tearing down afterwards does not unmake it
-                sys.stderr.write(f'bench.py: launcher exit code {rc} after the result line was relayed (teardown); reporting success\n')
-            return 0
+            if rc != 0:   # the result line is out, but a rank failed afterwards: the failure stays visible in our exit code
+                sys.stderr.write(f'bench.py: torch.distributed.run exited with {rc} after the result line was relayed\n')
+            return rc
     return rc or 1
 
 
@@ -238,19 +238,27 @@ def cpu_baseline(seed):
                                   f'({dt0 * 1e3:.1f} ms on 1 thread)'}}
 
 
-def load_profile(suffix, flying=False):
-    """Latest committed profile summary profiles/r*_<suffix> (walking) or r*_flying_<suffix> (json), or None."""
+def load_profile(suffix, kind='', library_build_id=None, profiles_dir=None):
+    """Latest committed profile summary profiles/r*_<suffix> (the headline workload), r*_flying_<suffix> or
+    r*_cdm_<suffix> (kind = 'flying' / 'cdm'), or None.
+    The summary carries the build id of the library it was taken with (tools/summarize_profile.py); `stale` says
+    whether that is another build than the one being timed (`library_build_id` = igw_build_id() of the loaded
+    library).  A profile without a build id (rounds 1-4) is stale by definition."""
     import glob
     best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_' + ('flying_' if flying else '') + suffix))):
-        if ('flying' in os.path.basename(p)) != flying:
-            continue
+    d = profiles_dir or os.path.join(ROOT, 'profiles')
+    kind = 'flying' if kind is True else (kind or '')
+    for p in sorted(glob.glob(os.path.join(d, 'r[0-9]*_' + (kind + '_' if kind else '') + suffix))):
+        if os.path.basename(p).split('_', 1)[1] != (kind + '_' if kind else '') + suffix:
+            continue   # (r05_flying_traffic.json is not a walking profile)
         try:
             with open(p) as f:
                 best = json.load(f)
             best['_file'] = os.path.relpath(p, ROOT)
         except Exception:
             pass
+    if best is not None:
+        best['stale'] = library_build_id is None or best.get('build_id') != library_build_id
     return best
 
 
@@ -279,8 +287,10 @@ def dry_run(args):
                               'max_elapsed': mx, 'windows_max': wins, 'steps': args.steps, 'warmup': args.warmup,
                               'config': {'ranks_seen': ranks, 'kernel_us_per_rank': kernel_us,
                                          'usable_cpus': usable_cpus(), 'torch_threads': _torch_threads()}}), flush=True)
-    finally:
-        gdist.shutdown()
+    except BaseException:
+        gdist.shutdown(barrier=False)
+        raise
+    gdist.shutdown()
 
 
 def _torch_threads():
@@ -313,10 +323,15 @@ class Runner:
         self.K, self.W = args.steps, args.warmup
         self.env_offset = rank * N  # rank-offset RNG streams / task seeds
         self.node_barrier = node_barrier
-        self.env = env = VecGridWorld(N, device=device, action_space=mode, size_reward=False, max_steps=MAX_STEPS,
+        # 'dummy' = BASELINE configs[1]: the DUMMY_TASK-equivalent target with gym.make's defaults (SizeReward on)
+        self.env = env = VecGridWorld(N, device=device, action_space=mode, size_reward=(workload == 'dummy'), max_steps=MAX_STEPS,
                                       autoreset=True, lanes_per_env=args.lanes_per_env, debug_flags=args.debug_flags,
                                       env_index_base=self.env_offset)
-        if workload == 'cdm':
+        if workload == 'dummy':   # tasks/task_set.py:160: one blue block at dense [8, 10, 10], invariant=False
+            dummy = torch.zeros((1, 9, 11, 11), dtype=torch.int8)
+            dummy[0, 8, 10, 10] = 1
+            env.set_tasks(dummy, invariant=False)
+        elif workload == 'cdm':
             import numpy as np
             tg, st = workloads.cdm(N, args.seed + rank, np.load(CDM_GOALS)['dense'])
             env.set_tasks(tg.to(device), st.to(device))
@@ -513,7 +528,7 @@ class Runner:
         if not self.args.lockstep:
             self.busy(0.3, 0)
         rehearsal_ms = [round(1e3 * self.window()[0] / K, 5) for _ in range(rehearsals)]
-        walls, kernels, ps, resets, cells = [], [], [], [], []
+        walls, kernels, ps, resets, cells, counted = [], [], [], [], [], []
         for _ in range(max(1, windows)):
             el, st0_dev, kms, host_tl = self.window()
             s0, s1 = st0_dev.cpu(), env.stats_buf.sum(0).cpu()
@@ -522,6 +537,7 @@ class Runner:
             ps.append(float(s1[L.STAT_CHANGED] - s0[L.STAT_CHANGED]) / (N * K))
             cells.append(float(s1[L.STAT_RESCANS] - s0[L.STAT_RESCANS]) / (N * K))
             resets.append(int(s1[L.STAT_RESETS] - s0[L.STAT_RESETS]))
+            counted.append(int(s1[L.STAT_STEPS] - s0[L.STAT_STEPS]))   # env-steps the kernels counted on the device
             if os.environ.get('IGW_BENCH_TRACE'):
                 print('host us: head launches %.1f | graph launch %.1f | ev1.record %.1f | spin %.1f | synchronize %.1f | '
                       'barrier %.1f | total %.1f | kernel %.2f us' % (tuple(1e6 * x for x in host_tl) + (1e6 * el, 1e3 * kms)),
@@ -535,57 +551,90 @@ class Runner:
                 'window_spread': (max(walls_max) - min(walls_max)) / med,
                 'rehearsal_ms_per_step': rehearsal_ms,
                 'kernel_ms': statistics.median(kernels), 'p_changed': ps[i_med], 'p_cell_changed': cells[i_med],
-                'resets_in_window': resets[i_med]}
+                'resets_in_window': resets[i_med], 'steps_counted': counted[i_med], 'steps_counted_all': counted}
 
 
-def roofline_of(r, m, lanes, has_start_frac=0.0):
-    """The roofline object of a measured workload (see the module docstring)."""
+HBM_ACHIEVABLE_GBS = 6300.0   # what a streaming kernel reaches on this part (MI355X_MICROARCH.md)
+
+
+def roofline_of(r, m, lanes, has_start_frac=0.0, profiles_dir=None):
+    """The roofline object of a measured workload.
+
+    `achieved` / `frac` are PHYSICAL: the HBM bytes one launch of the dominant kernel moves -- FETCH_SIZE / WRITE_SIZE
+    of the committed rocprofv3 PMC profile, corrected as MI355X_MICROARCH.md prescribes (tools/summarize_profile.py),
+    scaled to this run's env count -- over the kernel's average duration measured in THIS run with HIP events on the
+    launch stream, against the 8 TB/s peak.  The profile must be of the same kernel build: it carries the library's
+    build id (hash of csrc/ + include/igw.h + flags), and `stale` is true when that differs from igw_build_id() of the
+    library being timed.  Without any profile the design's byte count stands in (`basis` says so).
+
+    Beside it: `frac_of_achievable` (against the ~6.3 TB/s a streaming kernel reaches), `design_bytes_per_env_step`
+    (what this data layout has to move, counted below) and `wasted_traffic` = measured / design bytes, and the
+    SURVEY 8(d) convention figure (`convention`: the int8 grid priced as if streamed every step -- this design reads
+    a 192-byte bitmap of it instead, so that figure is not a physical fraction and can exceed 1)."""
+    from gridworld_amd import _lib as L
     N, flying = r.N, r.flying
     kernel_ms, p, pc = m['kernel_ms'], m['p_changed'], m['p_cell_changed']
+    kernel_s = kernel_ms * 1e-3
     resets_per_step = m['resets_in_window'] / float(N * r.K)
+    # SURVEY 8(d) convention
     bytes_per_step = (BYTES_BASE + (24 if flying else 0)) + BYTES_CHANGED * p  # flying actions are 28 B, not 4
-    achieved = N * bytes_per_step / (kernel_ms * 1e-3) / 1e9
-    # What this design has to move per env-step (DESIGN.md section 3/4): occupancy bitmap 192 r, agent record 64 r +
-    # 64 w, action 4 (28 flying), task index 4, outputs 53 w (agentPos 20, inventory 24, compass / reward 4 + 4, done
-    # 1); per changed cell: histogram row 1024 r, target level 128 + start byte 4 + boxes 16 r, about four 16-byte
-    # histogram pieces + 1 grid byte + 1 bitmap word w, the break's colour byte r; per auto-reset: starting grid row
-    # 1104 r (only with a starting grid), grid row 1104 w, bitmap 192 w (+ 192 r), histogram row 1024 w, metadata
-    # 128 r, agent record 64 w, observations 49 w.
-    base = 192 + 64 + 64 + (28 if flying else 4) + 4 + 53
-    per_cell = 1024 + 128 + 4 + 16 + 64 + 1 + 4 + 1
-    per_reset = 1104 + 192 + 1024 + 128 + 64 + 49 + has_start_frac * (1104 + 192)
+    conv_gbs = N * bytes_per_step / kernel_s / 1e9
+    # What this design has to move per env-step (DESIGN.md section 5): occupancy bitmap 192 r, agent record 64 r +
+    # 64 w, aux record 16 r, action 4 (28 flying), output record 64 w; per changed cell: histogram row 1024 r + 1024 w,
+    # colour-index block 160 r, start byte + break colour (one 32-byte sector each) 64 r, grid byte + bitmap word
+    # (one sector each) 64 w, aux record 16 w; per auto-reset: metadata 128 r, grid row 1104 w, bitmap 192 w,
+    # histogram row 1024 w, aux 16 w (+ starting row 1104 r and its bitmap 192 r with a starting grid).
+    base = 192 + 64 + 64 + 16 + (28 if flying else 4) + 64
+    per_cell = 1024 + 1024 + 160 + 64 + 64 + 16
+    per_reset = 128 + 1104 + 192 + 1024 + 16 + has_start_frac * (1104 + 192)
     design = base + pc * per_cell + resets_per_step * per_reset
-    achieved_design = N * design / (kernel_ms * 1e-3) / 1e9
-    traffic = load_profile('traffic.json', flying)
-    issue = load_profile('issue.json', flying)
+    lib_id = L.build_id()
+    kind = 'flying' if flying else ('cdm' if r.workload == 'cdm' else '')
+    traffic = load_profile('traffic.json', kind, lib_id, profiles_dir)
+    issue = load_profile('issue.json', kind, lib_id, profiles_dir)
     hbm_bytes = None if traffic is None else traffic.get('hbm_bytes_per_launch')
-    prof_envs = None if traffic is None else traffic.get('envs', ENVS_PER_GPU)
+    prof_envs = None if traffic is None else (traffic.get('envs') or ENVS_PER_GPU)
     if hbm_bytes is not None and prof_envs and prof_envs != N:
         hbm_bytes = hbm_bytes * N / prof_envs   # the committed profile is of the 65,536-env launch
+    basis = 'pmc' if hbm_bytes is not None else 'design'
+    moved = hbm_bytes if hbm_bytes is not None else N * design
+    achieved = moved / kernel_s / 1e9
+    stale = None if traffic is None else bool(traffic['stale'])
     roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': hbm_bytes,
+            'basis': {'pmc': 'HBM bytes per launch from the committed rocprofv3 PMC profile (FETCH_SIZE x 2 + WRITE_SIZE, KiB) '
+                             '/ kernel_avg_ms of this run', 'design': 'no PMC profile found: the design byte count / kernel_avg_ms'}[basis],
+            'stale': stale,
+            'frac_of_achievable': achieved / HBM_ACHIEVABLE_GBS, 'achievable_gbs': HBM_ACHIEVABLE_GBS,
             # <lanes per env, action space, extras, flying's whole-blocks variant> (csrc/igw_kernels.hip)
             'kernel': 'igw::step_kernel<%d, %d, false, %s>' % (lanes, 1 if flying else 0,
                                                               'true' if flying and lanes == 4 and N % 64 == 0 else 'false'),
             'kernel_avg_ms': kernel_ms,
-            'algorithmic_bytes_per_env_step': bytes_per_step,
-            'algorithmic_bytes_per_launch': N * bytes_per_step,
-            # the same kernel time against what this design must move: the kernel is NOT HBM-bound
-            'design_bytes_per_env_step': design, 'achieved_design': achieved_design,
-            'frac_design': achieved_design / HBM_PEAK_GBS,
-            'hbm_measured_gbs': None if hbm_bytes is None else hbm_bytes / (kernel_ms * 1e-3) / 1e9,
-            'hbm_measured_frac': None if hbm_bytes is None else hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            'limiter': 'issue',   # see the `issue` object: instruction issue of the waves sharing a SIMD
-            'measured_in_this_run': ['achieved', 'frac', 'kernel_avg_ms', 'algorithmic_bytes_per_env_step',
-                                     'design_bytes_per_env_step', 'achieved_design', 'frac_design'],
-            'from_profile': {'fields': ['traffic', 'hbm_measured_gbs (bytes of the profile / this run\'s kernel time)',
-                                        'hbm_measured_frac'],
-                             'source': None if traffic is None else traffic.get('_file')}}
+            'design_bytes_per_env_step': design, 'design_bytes_per_launch': N * design,
+            'frac_design': N * design / kernel_s / 1e9 / HBM_PEAK_GBS,
+            'wasted_traffic': None if hbm_bytes is None else hbm_bytes / (N * design),
+            'profile': None if traffic is None else {
+                'source': traffic.get('_file'), 'build_id': traffic.get('build_id'), 'git_commit': traffic.get('git_commit'),
+                'library_build_id': lib_id, 'stale': stale, 'envs': prof_envs,
+                'kernel_avg_ns_under_rocprof': traffic.get('kernel_avg_ns'),
+                # reproducible from profiles/ alone: the profile's bytes over the profile's own kernel time
+                'frac_in_profile_run': (None if not traffic.get('kernel_avg_ns') or traffic.get('hbm_bytes_per_launch') is None else
+                                        traffic['hbm_bytes_per_launch'] / (traffic['kernel_avg_ns'] * 1e-9) / 1e9 / HBM_PEAK_GBS)},
+            'convention': {'what': 'SURVEY.md 8(d): 1274 + 1106 p bytes per env-step (1298 flying), the int8 grid priced as streamed '
+                                   'every step; this design keeps a 192-byte occupancy bitmap of it, so the figure is not a physical '
+                                   'fraction (it exceeds 1 at large launches) -- kept for comparison across rounds',
+                           'algorithmic_bytes_per_env_step': bytes_per_step, 'algorithmic_bytes_per_launch': N * bytes_per_step,
+                           'achieved': conv_gbs, 'frac': conv_gbs / HBM_PEAK_GBS},
+            'frac_convention': conv_gbs / HBM_PEAK_GBS,
+            'limiter': 'issue',   # see `issue`: the kernel is bound by instruction issue of the waves sharing a SIMD, not by HBM
+            'measured_in_this_run': ['kernel_avg_ms', 'design_bytes_per_env_step (p_changed, resets counted on the device)',
+                                     'convention'],
+            'from_profile': ['traffic', 'issue.*_per_wave']}
     iss = None
     if issue is not None:
         valu = issue.get('valu_insts_per_wave')
         waves_per_simd = (N * lanes / 64.0) / 1024.0   # 256 CUs x 4 SIMDs
-        iss = {'bound': 'issue', 'source': issue.get('_file'),
+        iss = {'bound': 'issue', 'source': issue.get('_file'), 'build_id': issue.get('build_id'), 'stale': bool(issue['stale']),
                'from_profile': {k: issue.get(k) for k in ('valu_insts_per_wave', 'salu_insts_per_wave', 'lds_insts_per_wave',
                                                           'vmem_rd_insts_per_wave', 'vmem_wr_insts_per_wave',
                                                           'frac_wave_time_parked_on_waitcnt', 'frac_wave_time_issue_stalled',
@@ -593,20 +642,49 @@ def roofline_of(r, m, lanes, has_start_frac=0.0):
                'waves_per_simd': waves_per_simd,
                # one VALU instruction occupies its SIMD for 4 cycles: share of THIS run's kernel time the SIMDs spend
                # issuing VALU instructions (instruction count of the profile, kernel time of this run)
-               'valu_issue_util_per_simd': None if not valu else valu * waves_per_simd * 4.0 / (kernel_ms * 1e-3 * GPU_CLOCK_GHZ * 1e9),
+               'achieved': None if not valu else valu * waves_per_simd * 4.0 / (kernel_s * GPU_CLOCK_GHZ * 1e9),
+               'peak': 1.0, 'unit': 'VALU issue cycles per SIMD cycle',
+               'valu_issue_util_per_simd': None if not valu else valu * waves_per_simd * 4.0 / (kernel_s * GPU_CLOCK_GHZ * 1e9),
                'valu_insts_per_env_step': None if not valu else valu * lanes / 64.0}
-    # the bound that binds, inside `roofline` itself: the issue side and the measured HBM side next to the convention
+    roof['issue'] = iss
     roof['issue_util'] = None if iss is None else iss['valu_issue_util_per_simd']
-    roof['hbm_frac_measured'] = roof['hbm_measured_frac']
-    roof['note'] = ('`frac` follows the SURVEY 8(d) convention (the 1,089-byte int8 grid priced every step); this design keeps a '
-                    '192-byte occupancy bitmap of it and streams ~0.5 KB per env-step, so `frac` rises with any speed-up and '
-                    'exceeds 1 at 524,288 envs per launch (1.2) although no work is skipped -- the bytes are not moved. '
-                    'The kernel is bound by instruction issue: a wavefront issues about one instruction per 11 cycles (its '
-                    'next one depends on the last) and the four wavefronts of a SIMD keep its vector ALU busy for `issue_util` '
-                    'of the launch (VALU instructions per wavefront of the committed SQ profile x 4 cycles x 4 wavefronts over '
-                    'this run\'s kernel time); `hbm_frac_measured` = PMC bytes of the committed profile / this run\'s kernel '
-                    'time / peak.')
     return roof, iss
+
+
+def facade_rate(seed, steps=3000):
+    """The latency end of the API -- BASELINE configs[0] through the reference's own calling sequence on the HIP path:
+    gridworld_amd.make('IGLUGridworldVector-v0') (create_env defaults: Discrete(18), SizeReward, select_and_place), the
+    DUMMY_TASK-equivalent task, `obs, reward, done, info = env.step(int)` with numpy observations, reset on done.
+    Every step is one HIP-graph replay (action upload, step kernel, 1.2 KB read-back) + one stream synchronisation.
+    Timed as examples/run_env.py:18-26 does (step() only) and including the resets."""
+    import numpy as np
+    import gridworld_amd as G
+    env = G.make('IGLUGridworldVector-v0')
+    dummy = np.zeros((9, 11, 11), np.int32)
+    dummy[8, 10, 10] = 1
+    env.set_task(G.Task('', dummy, starting_grid=[], invariant=False))
+    env.reset()
+    acts = [int(a) for a in np.random.RandomState(seed).randint(18, size=steps + 300)]
+    for a in acts[:300]:   # warm: graph capture, code paths
+        if env.step(a)[2]:
+            env.reset()
+    t_step, n_reset = 0.0, 0
+    t0 = time.perf_counter()
+    for a in acts[300:]:
+        ts = time.perf_counter()
+        obs, reward, done, info = env.step(a)
+        t_step += time.perf_counter() - ts
+        if done:
+            env.reset()
+            n_reset += 1
+    wall = time.perf_counter() - t0
+    return {'workload': 'configs[0]: 1 env, walking Discrete(18), DUMMY_TASK-equivalent task, gym.make defaults, numpy '
+                        'observations, reset on done',
+            'steps': steps, 'resets': n_reset, 'steps_per_s_step_only': steps / t_step, 'steps_per_s_incl_resets': steps / wall,
+            'us_per_step': 1e6 * t_step / steps, 'graph': env.unwrapped._graph is not None,
+            'how': 'one HIP-graph replay (action upload, step_kernel<32,...>, 1.2 KB read-back into pinned memory) + one '
+                   'stream synchronisation per step',
+            'reference_python_here': 'BASELINE.md: 3.8-4.2 k steps/s step only, 2.9-3.2 k incl. resets (build container, 1 core)'}
 
 
 def main():
@@ -618,8 +696,12 @@ def main():
     from gridworld_amd import dist as gdist
     try:
         run(args)
-    finally:
-        gdist.shutdown()   # closing barrier + destroy_process_group: no rank falls off the end while others still talk
+    except BaseException:
+        # A rank that failed must not wait for peers that are still inside a collective or the shared-memory barrier:
+        # no closing barrier, tear our side down and leave non-zero at once -- torchrun then ends the other ranks.
+        gdist.shutdown(barrier=False)
+        raise
+    gdist.shutdown()   # success: closing barrier (gloo) + destroy_process_group, so no rank falls off the end early
 
 
 def run(args):
@@ -644,9 +726,16 @@ def run(args):
     r = Runner(args, args.mode, args.workload, device, rank, world, node_barrier)
     env = r.env
     m = r.measure(args.windows, args.rehearsals)
-    total_steps = N * K * world
     max_elapsed = m['elapsed']
-    ranks_seen, gather_via = gdist.gather_counts_rccl(rank, device)   # the one RCCL collective: per-rank step counts
+    # The one RCCL collective of the run (north star): every rank's DEVICE-SIDE step count of the median window --
+    # the delta of IGW_STAT_STEPS, which the step kernels add to once per block -- gathered over RCCL / xGMI; `value`
+    # is computed from their sum, and the sum must be what the launches were asked to do.
+    steps_per_rank, gather_via = gdist.gather_counts_rccl(m['steps_counted'], device)
+    total_steps = sum(steps_per_rank)
+    if any(c != N * K for c in m['steps_counted_all']) or total_steps != N * K * world:
+        raise SystemExit(f'device step counters disagree with the launches: windows {m["steps_counted_all"]}, '
+                         f'per rank {steps_per_rank}, expected {N * K} per rank and window')
+    ranks_seen = gdist.gather_counts(rank)   # (control plane)
     n_ranks = len(ranks_seen)
     kernel_us_per_rank = [round(x, 3) for x in gdist.gather_floats(1e3 * m['kernel_ms'])]   # (control plane)
     api = r.api_loops() if not args.no_api else None
@@ -743,11 +832,35 @@ def run(args):
                 'windows_ms_per_step': m2['windows_ms_per_step'], 'kernel_us': 1e3 * m2['kernel_ms'],
                 'p_changed': m2['p_changed'], 'p_cell_changed': m2['p_cell_changed'],
                 'resets_in_window': m2['resets_in_window'], 'timed_as': r2.timed_as,
-                'roofline': {k: roof2[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel',
-                                                   'kernel_avg_ms', 'design_bytes_per_env_step', 'frac_design', 'limiter')},
+                'roofline': {k: roof2[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'basis', 'stale', 'kernel',
+                                                   'kernel_avg_ms', 'design_bytes_per_env_step', 'wasted_traffic', 'frac_of_achievable',
+                                                   'frac_convention', 'profile', 'limiter')},
                 'valu_issue_util_per_simd': None if iss2 is None else iss2['valu_issue_util_per_simd']}
             del r2
             torch.cuda.empty_cache()
+
+    # the latency end: BASELINE configs[1] (4,096 envs, DUMMY_TASK-equivalent, gym.make defaults) through the same
+    # window machinery, and configs[0] through the 1-env gym facade
+    small = facade = None
+    if world == 1 and not args.no_secondary and not flying and args.workload == 'rt20' and not args.debug_flags:
+        Ns = 4096
+        r3 = Runner(args, 'walking', 'dummy', device, rank, world, node_barrier, N=Ns)
+        m3 = r3.measure(max(3, args.windows // 2), 2)
+        lanes3 = r3.env.cfg.lanes_per_env or auto_lanes(Ns)
+        waves3 = Ns * lanes3 // 64
+        small = {'workload': 'configs[1]: 4,096 parallel envs, walking Discrete(18), DUMMY_TASK-equivalent task (one blue block at '
+                             'dense [8,10,10], invariant=False), gym.make defaults (SizeReward, select_and_place), uniform random '
+                             'actions, auto-reset at done (max_steps=250)',
+                 'value': Ns * K / m3['elapsed'], 'unit': 'env-steps/s', 'ms_per_step': 1e3 * m3['elapsed'] / K,
+                 'windows_ms_per_step': m3['windows_ms_per_step'], 'kernel_us': 1e3 * m3['kernel_ms'],
+                 'kernel': 'igw::step_kernel<%d, 0, false, false>' % lanes3, 'lanes_per_env': lanes3, 'wavefronts': waves3,
+                 'p_changed': m3['p_changed'], 'resets_in_window': m3['resets_in_window'], 'timed_as': r3.timed_as,
+                 'bound': 'latency: %d wavefronts for 1,024 SIMDs run as ONE round, so a launch lasts the launch ramp + the '
+                          'dependent instruction chain of one wavefront (wider groups shorten the chain: %d lanes per env); '
+                          'env-steps/s per env is highest here, per GPU lowest' % (waves3, lanes3)}
+        del r3
+        torch.cuda.empty_cache()
+        facade = facade_rate(args.seed)
 
     if rank != 0:
         return None
@@ -793,7 +906,8 @@ def run(args):
                    'rehearsal_ms_per_step': m['rehearsal_ms_per_step'],
                    'resets_in_window': m['resets_in_window'], 'p_changed': m['p_changed'],
                    'p_cell_changed': m['p_cell_changed'],
-                   'step_count_gather': gather_via, 'ranks_seen': ranks_seen, 'kernel_us_per_rank': kernel_us_per_rank,
+                   'step_count_gather': gather_via, 'device_step_counts_per_rank': steps_per_rank,
+                   'ranks_seen': ranks_seen, 'kernel_us_per_rank': kernel_us_per_rank,
                    'host': {'usable_cpus': usable_cpus(), 'torch_threads': torch.get_num_threads()},
                    'fused_rollout_env_steps_per_s': fused,
                    'fused_rollout_recorded_actions_env_steps_per_s': fused_rec,
@@ -813,6 +927,10 @@ def run(args):
         if 'graph_error' in api:
             out['config']['api_graph_error'] = api['graph_error']
     out['config'].update(secondary)
+    if small is not None:
+        out['config']['small'] = small
+    if facade is not None:
+        out['config']['facade_1env'] = facade
     if iss is not None:
         out['issue'] = iss
     if world == 1 and not args.no_cpu_baseline:

@@ -21,7 +21,7 @@ TRAJ_BYTES = 64
 HIST_ROW = 512
 STAT_STRIPES = 64
 STAT_CHANGED, STAT_RESETS, STAT_STEPS, STAT_RESCANS, STAT_BAD_POSE, STAT_BAD_ACTION, STAT_BAD_TASK = 0, 1, 2, 3, 4, 5, 6
-VERSION = 4
+VERSION = 5
 LEVEL_INDEX_BYTES = 160
 TASK_INDEX_BYTES = 9 * LEVEL_INDEX_BYTES
 WALKING_DISCRETE, FLYING, WALKING_DICT = 0, 1, 2
@@ -29,7 +29,7 @@ RESET_KEEP_SIZE = 1
 CAMERA_MAX = 1e6   # IGW_CAMERA_MAX
 
 # every symbol include/igw.h declares (checked by tests/test_abi.py)
-EXPORTS = ['igw_version', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',
+EXPORTS = ['igw_version', 'igw_build_id', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',
            'igw_bind_buffers', 'igw_prepare_tasks', 'igw_set_task_sampling', 'igw_set_random_tasks',
            'igw_set_trajectory_log', 'igw_reset', 'igw_step_walking', 'igw_step_flying', 'igw_step_walking_dict',
            'igw_rollout_walking', 'igw_rollout_walking_actions', 'igw_rollout_flying_actions', 'igw_fill_actions_walking', 'igw_task_eval', 'igw_debug_trig']
@@ -80,6 +80,7 @@ def load(build_if_missing=True):
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     L.igw_version.restype = C.c_int
     L.igw_last_error.restype = C.c_char_p
+    L.igw_build_id.restype = C.c_char_p
     L.igw_device_count.restype = C.c_int
     L.igw_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.igw_destroy.argtypes = [vp]
@@ -101,10 +102,15 @@ def load(build_if_missing=True):
     L.igw_debug_trig.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)
-        if name not in ('igw_last_error',):
+        if name not in ('igw_last_error', 'igw_build_id'):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def build_id():
+    """igw_build_id() of the loaded library (hash of the kernel sources it was compiled from)."""
+    return load().igw_build_id().decode()
 
 
 def check(code, what=''):

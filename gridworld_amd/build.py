@@ -34,12 +34,42 @@ def hipcc():
     raise RuntimeError('hipcc not found')
 
 
-def is_stale(lib=LIB):
+def source_hash(diag=False):
+    """Identity of a kernel build: sha256 over the kernel sources, include/igw.h and the compiler flags (16 hex
+    digits).  It is compiled into the library (-DIGW_BUILD_ID, exported as igw_build_id()) and stamped on every
+    profile summary under profiles/ (tools/summarize_profile.py), so a bench line can tell whether the PMC bytes it
+    quotes were measured on the kernels it timed."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(f).encode() + b'\0')
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()[:16] + ('-diag' if diag else '')
+
+
+def built_id(lib=LIB):
+    """igw_build_id() of an existing library file, read without loading it (the id string follows a marker)."""
+    try:
+        with open(lib, 'rb') as f:
+            data = f.read()
+        i = data.find(b'igw-build-id:')
+        if i < 0:
+            return None
+        j = data.index(b'\0', i)
+        return data[i + len(b'igw-build-id:'):j].decode()
+    except (OSError, ValueError):
+        return None
+
+
+def is_stale(lib=LIB, diag=False):
+    """Missing, older than a source (mtime), or built from other sources than the ones on disk (build id)."""
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in deps) or built_id(lib) != source_hash(diag)
 
 
 def build(force=False, extra_flags=(), verbose=False, diag=False):
@@ -49,13 +79,14 @@ def build(force=False, extra_flags=(), verbose=False, diag=False):
     lib = LIB_DIAG if diag else LIB
     if diag:
         extra_flags = tuple(extra_flags) + ('-DIGW_DIAG',)
-    if not force and not is_stale(lib):
+    extra_flags = tuple(extra_flags) + ('-DIGW_BUILD_ID="igw-build-id:%s"' % source_hash(diag),)
+    if not force and not is_stale(lib, diag):
         return lib
     import fcntl
     with open(lib + '.lock', 'w') as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not is_stale(lib):  # another process built it while we waited
+            if not force and not is_stale(lib, diag):  # another process built it while we waited
                 return lib
             tmp = f'{lib}.tmp.{os.getpid()}'
             cmd = [hipcc()] + FLAGS + list(extra_flags) + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]

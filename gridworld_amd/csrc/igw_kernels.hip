@@ -1200,7 +1200,7 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
                                  bool active, Env& e, const CellChange& ch, int task, int env_max_int, int size_new, int mi,
                                  bool need, bool changed, int8_t* grid_g, const uint32_t* occ_s, bool boost,
                                  [[maybe_unused]] int diag_m, ResetMeta rm, bool pre_ok, const TailParams& tp, int size_in,
-                                 int staged_leader, uint32_t staged_occ) {
+                                 int staged_leader, uint32_t staged_occ, int block_envs) {
     const StepOut o = finish_step(tp, e, env_max_int, size_new, mi);
     const bool do_reset = active && o.done && tp.autoreset;
     // the stores of an env whose episode goes on (`keep`); the counters of the wavefront
@@ -1227,8 +1227,11 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
     const auto counters = [&]() {   // one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
         const uint64_t m_need = __ballot(need && active && G.gl == 0), m_cell = __ballot(ch.idx >= 0 && active && G.gl == 0),
                        m_reset = __ballot(do_reset && G.gl == 0);
-        if ((m_need | m_cell | m_reset) != 0 && tp.stats != nullptr && G.lane == 0) {
+        // IGW_STAT_STEPS: the env-steps of the block, added once per block by its first wavefront (scalar condition) --
+        // the device-side count of the work a launch did (bench.py gathers its per-rank delta over RCCL)
+        if (((m_need | m_cell | m_reset) != 0 || wave == 0) && tp.stats != nullptr && G.lane == 0) {
             unsigned long long* st = tp.stats + (blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8;
+            if (wave == 0) counter_add(st + IGW_STAT_STEPS, (unsigned long long)block_envs);
             if (m_need) counter_add(st + IGW_STAT_CHANGED, (unsigned long long)__builtin_popcountll(m_need));
             if (m_cell) counter_add(st + IGW_STAT_RESCANS, (unsigned long long)__builtin_popcountll(m_cell));
             if (m_reset) counter_add(st + IGW_STAT_RESETS, (unsigned long long)__builtin_popcountll(m_reset));
@@ -1534,7 +1537,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     stamp(p, 5);
     prio_at<true, 6>(boost);
     // (KParams sits behind the preloaded head arguments: kernarg_again reads it at that offset of the kernarg segment)
-    tail_step<GS, MODE, EXTRA>(G, kernarg_again<STEP_KERNARG_HEAD>(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp, size_in, staged_leader, staged_occ);
+    tail_step<GS, MODE, EXTRA>(G, kernarg_again<STEP_KERNARG_HEAD>(p), a, sh, wave, env, active, e, ch, task, env_max_int, size_new, mi, need, changed, grid_g, occ_s, boost, diag_m, pre, pre_ok, tp, size_in, staged_leader, staged_occ,
+                              EXACT ? BlockShared<GS>::EPB : min(BlockShared<GS>::EPB, n_envs - (int)blockIdx.x * BlockShared<GS>::EPB));
 }
 
 // T fused walking steps, state resident in registers + LDS.  Actions: counter RNG (auto-reset on done), or -- with
@@ -1968,6 +1972,11 @@ __global__ void debug_trig_kernel(int64_t n, const double* __restrict__ a, const
 extern "C" {
 
 int igw_version(void) { return IGW_VERSION; }
+#ifndef IGW_BUILD_ID
+#define IGW_BUILD_ID "igw-build-id:unstamped"
+#endif
+// (the string carries a marker so that build.py can read the id of a library file without loading it)
+const char* igw_build_id(void) { return IGW_BUILD_ID + sizeof("igw-build-id:") - 1; }
 const char* igw_last_error(void) { return g_err; }
 
 int igw_device_count(void) {

@@ -43,9 +43,9 @@ def shard_envs(total_envs, rank, world):
 
 
 def barrier(device=None):
-    """Control-plane barrier (gloo when the group has a CPU backend; `device` is accepted for old callers)."""
-    if dist.is_initialized():
-        dist.barrier()
+    """Control-plane barrier: explicitly over gloo when the group has a CPU backend (ctl_barrier); `device` is
+    accepted for old callers."""
+    ctl_barrier()
 
 
 class NodeBarrier:
@@ -97,14 +97,28 @@ class NodeBarrier:
                         raise RuntimeError('NodeBarrier: rank %d timed out waiting for the others' % self.rank)
 
 
-def shutdown():
-    """Closing barrier + destroy_process_group: every rank leaves together (a rank that falls off the end of main while
-    others are still inside a collective aborts them at teardown)."""
+def ctl_barrier():
+    """Barrier over the CONTROL plane only: an all-reduce of a CPU tensor (gloo).  dist.barrier() on a mixed
+    cpu:gloo,cuda:nccl group may pick the NCCL side and then needs every rank's GPU stream to be alive."""
+    if not dist.is_initialized():
+        return
+    if _cpu_ok():
+        dist.all_reduce(torch.zeros(1, dtype=torch.int64))
+    else:
+        dist.barrier()
+
+
+def shutdown(barrier=True):
+    """destroy_process_group, after a closing control-plane barrier on the SUCCESS path (every rank leaves together: a
+    rank that falls off the end of main while others are still inside a collective aborts them at teardown).  A rank
+    that failed passes barrier=False: its peers are still in a collective or in the NodeBarrier spin and would never
+    reach a closing barrier -- it must go down at once so that torchrun ends the group."""
     if dist.is_initialized():
-        try:
-            dist.barrier()
-        except Exception:  # noqa: BLE001 -- a peer already gone: still tear our side down
-            pass
+        if barrier:
+            try:
+                ctl_barrier()
+            except Exception:  # noqa: BLE001 -- a peer already gone: still tear our side down
+                pass
         try:
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001

@@ -1,27 +1,124 @@
-"""1-env, gym-shaped facade over the HIP path: same construction kwargs, methods, observation dict,
-dtypes and errors as the reference's `GridWorld` + `SizeReward` + `create_env`
-(gridworld/env.py:26-362) for render=False.  It drives a VecGridWorld with N = 1 and copies the
-1.2 KB observation to the host each step, so it is for API parity, not for speed."""
+"""1-env, gym-shaped facade over the HIP path: the reference's `GridWorld`, `Wrapper`, `SizeReward`, `create_env` and
+the two registered ids (gridworld/env.py:26-362) for render=False -- same construction kwargs, methods, attributes,
+observation dict, dtypes and errors.
+
+    env = gridworld_amd.make('IGLUGridworld-v0', vector_state=True, render=False)   # SizeReward(GridWorld(...))
+    env.set_task(task); obs = env.reset(); obs, reward, done, info = env.step(action)
+    env.unwrapped            # the GridWorld; .agent / .world / .grid / .step_no / .max_int as in the reference
+
+It drives a VecGridWorld with N = 1.  A step is ONE replay of a captured HIP graph -- action host -> device, the step
+kernel, one device -> host copy of the env's records and grid (VecGridWorld.host_view, 1.2 KB, into pinned memory)
+-- and one stream synchronisation; the observation arrays are fresh numpy copies, as the reference's are."""
+import ctypes as C
 import warnings
 
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import spaces
 from .tasks import Task, Tasks
 from .vec_env import VecGridWorld
 
+_HIP_H2D, _HIP_D2H = 1, 2   # hipMemcpyKind
+
+
+def _hip_runtime():
+    """The HIP runtime torch already loaded, for hipMemcpyAsync (plumbing: two tiny copies per step that must be
+    capturable into a graph without the caching host allocator's bookkeeping)."""
+    rt = C.CDLL('libamdhip64.so')
+    rt.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    rt.hipMemcpyAsync.restype = C.c_int
+    return rt
+
+
 _NO_TASK = ('Task is not initialized! Initialize task before working with the environment using .set_task '
             'method OR set tasks distribution using .set_task_generator method')
+_TIS = (2, 4, 8, 12)
+
+
+class AgentView:
+    """Read-only view of the env's `Agent` (gridworld/core/world.py:8-29) as of the last reset / step: position
+    (x, y, z), rotation (yaw, pitch), dy, time_int_steps, inventory (list of 6 ints), active_block, flying, strafe,
+    sustain -- float64 / int values straight from the device's agent record (include/igw.h)."""
+    PAD = 0.25
+    __slots__ = ('_env',)
+
+    def __init__(self, env):
+        self._env = env
+
+    def _f64(self):
+        return self._env._host['agent'][:48].view(np.float64)
+
+    @property
+    def position(self):
+        f = self._f64()
+        return (float(f[0]), float(f[1]), float(f[2]))
+
+    @property
+    def rotation(self):
+        f = self._f64()
+        return (float(f[3]), float(f[4]))
+
+    @property
+    def dy(self):
+        return float(self._f64()[5])
+
+    @property
+    def inventory(self):
+        return [int(v) for v in self._env._host['agent'][48:60].view(np.int16)]
+
+    @property
+    def time_int_steps(self):
+        return _TIS[int(self._env._host['agent'][62:64].view(np.uint16)[0]) & 3]
+
+    @property
+    def active_block(self):
+        return (int(self._env._host['agent'][62:64].view(np.uint16)[0]) >> 2) & 7
+
+    @property
+    def flying(self):
+        return self._env.action_space_type == 'flying'
+
+    strafe = property(lambda self: [0, 0])   # reset at the end of every update (core/world.py:217-218)
+    sustain = property(lambda self: False)
+    reticle = property(lambda self: None)
+
+
+class WorldView:
+    """Read-only view of the env's `World` (gridworld/core/world.py:31-71): `world` = {(x, y, z): texture id} of the
+    ground plane (37 x 37 at y = -2: WHITE -1 inside the build zone's footprint, GREY 0 around it, :60-71) and of the
+    blocks in the build zone, `placed` = the set of the latter's positions; rebuilt from the grid on access."""
+    __slots__ = ('_env',)
+    initialized = True
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def placed(self):
+        g = self._env.grid
+        return {(int(x) - 5, int(y) - 1, int(z) - 5) for y, x, z in zip(*np.nonzero(g))}
+
+    @property
+    def world(self):
+        w = {(x, -2, z): (-1 if abs(x) <= 5 and abs(z) <= 5 else 0) for x in range(-18, 19) for z in range(-18, 19)}
+        g = self._env.grid
+        for y, x, z in zip(*np.nonzero(g)):
+            w[(int(x) - 5, int(y) - 1, int(z) - 5)] = int(g[y, x, z])
+        return w
+
+    def build_zone(self, x, y, z, pad=0):   # core/world.py:57-58
+        return -5 - pad <= x <= 5 + pad and -5 - pad <= z <= 5 + pad and -1 - pad <= y < 8 + pad
 
 
 class GridWorld:
-    """create_env(...) of the reference (defaults of gridworld/env.py:333-338)."""
+    """The reference's GridWorld(Env) (gridworld/env.py:26-303), its own defaults included (select_and_place=False,
+    discretize=False, vector_state=True -- create_env's differ, env.py:333-338)."""
 
-    def __init__(self, render=True, discretize=True, size_reward=True, select_and_place=True,
-                 right_placement_scale=1, render_size=(64, 64), target_in_obs=False, vector_state=False,
-                 max_steps=250, action_space='walking', wrong_placement_scale=0.1, name='', fake=False,
-                 device='cuda:0'):
+    def __init__(self, render=True, max_steps=250, select_and_place=False, discretize=False, right_placement_scale=1.,
+                 wrong_placement_scale=0.1, render_size=(64, 64), target_in_obs=False, action_space='walking',
+                 vector_state=True, fake=False, name='', device='cuda:0'):
         if render and not fake:
             raise NotImplementedError('the renderer is out of scope of the MI355X step path; pass render=False '
                                       "(or use 'IGLUGridworldVector-v0')")
@@ -30,14 +127,13 @@ class GridWorld:
         self.max_steps, self.select_and_place, self.discretize = max_steps, select_and_place, discretize
         self.action_space_type = action_space
         # kept with the caller's types: the reference's reward is `int * scale` (env.py:293-296), a Python int
-        # for the default right_placement_scale=1 and a float for wrong_placement_scale=0.1
+        # for right_placement_scale=1 and a float for wrong_placement_scale=0.1
         self.right_placement_scale, self.wrong_placement_scale = right_placement_scale, wrong_placement_scale
-        self.size_reward = bool(size_reward)
         self.right_placement = self.wrong_placement = 0
+        # the device never computes SizeReward here: it is the reference's Python wrapper around this env (below)
         self._vec = VecGridWorld(1, device=device, action_space=action_space, select_and_place=select_and_place,
-                                 size_reward=size_reward, max_steps=max_steps,
-                                 right_placement_scale=right_placement_scale, discretize=discretize,
-                                 wrong_placement_scale=wrong_placement_scale, num_tasks=1)
+                                 size_reward=False, max_steps=max_steps, right_placement_scale=right_placement_scale,
+                                 discretize=discretize, wrong_placement_scale=wrong_placement_scale, num_tasks=1)
         self._task = None
         self._task_generator = None
         self._overwrite_starting_grid = None
@@ -46,6 +142,9 @@ class GridWorld:
         self.starting_grid = None
         self.max_int = 0
         self.prev_grid_size = 0
+        self.renderer = None
+        self.agent = AgentView(self)
+        self.world = WorldView(self)
         if action_space == 'walking' and discretize:
             self.action_space = spaces.Discrete(18)
         elif action_space == 'walking':  # env.py:60-70
@@ -72,10 +171,102 @@ class GridWorld:
         if render:
             obs['pov'] = spaces.Box(low=0, high=255, shape=(*render_size, 3), dtype=np.uint8)
         self.observation_space = spaces.Dict(obs)
+        self._init_host_path()
+
+    # -- the host <-> device path of one step ---------------------------------------------------------------------
+    def _init_host_path(self):
+        """Pinned host mirrors of the env's records + grid (one device -> host copy per step) and of the action (one
+        host -> device copy), and the numpy views the Python side reads / writes."""
+        v = self._vec
+        dev = v.device
+        self._pin = torch.zeros(v.host_view.numel(), dtype=torch.uint8).pin_memory()
+        h = self._pin.numpy()
+        o, a, x = L.OUT_BYTES, L.AGENT_BYTES, L.AUX_BYTES
+        self._host = {'out': h[:o], 'agent': h[o:o + a], 'aux': h[o + a:o + a + x],
+                      'grid': h[o + a + x:o + a + x + L.CELLS].view(np.int8)}
+        self._out_f32 = self._host['out'][:52].view(np.float32)
+        self._aux_i16 = self._host['aux'][:8].view(np.int16)
+        # action staging, 40 bytes: walking action i32 / Dict buttons u8[8] at 0, camera f32[2] at 8, movement f32[3]
+        # at 16, inventory i32 at 28, placement i32 at 32
+        self._act_pin = torch.zeros(40, dtype=torch.uint8).pin_memory()
+        self._act_dev = torch.zeros(40, dtype=torch.uint8, device=dev)
+        ah = self._act_pin.numpy()
+        self._act = {'walk': ah[0:4].view(np.int32), 'buttons': ah[0:8], 'camera': ah[8:16].view(np.float32),
+                     'movement': ah[16:28].view(np.float32), 'inventory': ah[28:32].view(np.int32),
+                     'placement': ah[32:36].view(np.int32)}
+        self._graph = None
+        self._graph_epoch = -1
+        self._stream = torch.cuda.Stream(device=dev)   # the env's own stream: step() never waits for other work
+        self._hip = _hip_runtime()
+        self._read_back()   # a fresh Agent (core/world.py:12-29): inventory 20 x 6, BLUE active, time_int_steps 2
+
+    def _issue_step(self):
+        """action host -> device, the step kernel, records + grid device -> host; all on the env's stream."""
+        v, h = self._vec, C.c_void_p(self._stream.cuda_stream)
+        cp = self._hip.hipMemcpyAsync
+        if cp(self._act_dev.data_ptr(), self._act_pin.data_ptr(), self._act_pin.numel(), _HIP_H2D, h):
+            raise L.IgwError('hipMemcpyAsync (action) failed')
+        self._launch_step(h)
+        if cp(self._pin.data_ptr(), v.host_view.data_ptr(), self._pin.numel(), _HIP_D2H, h):
+            raise L.IgwError('hipMemcpyAsync (read-back) failed')
+
+    def _launch_step(self, stream_handle):
+        v, p = self._vec, self._act_dev.data_ptr()
+        if v.flying:
+            rc = v.lib.igw_step_flying(v.ctx, p + 16, p + 8, p + 28, p + 32, stream_handle)
+        elif v.walk_dict:
+            rc = v.lib.igw_step_walking_dict(v.ctx, p, p + 8, stream_handle)
+        else:
+            rc = v.lib.igw_step_walking(v.ctx, p, stream_handle)
+        L.check(rc, 'igw_step (facade)')
+
+    def _capture(self):
+        """action copy + step kernel + read-back as one HIP graph (re-captured when the episode log is switched:
+        a captured launch carries the kernel parameters by value, VecGridWorld.config_epoch)."""
+        v = self._vec
+        g = torch.cuda.CUDAGraph()
+        self._stream.synchronize()
+        try:
+            with torch.cuda.graph(g, stream=self._stream, capture_error_mode='thread_local'):
+                self._issue_step()
+            self._graph = g
+        except Exception:   # noqa: BLE001 -- no graph: the same three operations are issued one by one
+            self._graph = None
+            torch.cuda.synchronize(v.device)
+        self._graph_epoch = v.config_epoch
+
+    def _device_step(self):
+        v = self._vec
+        if self._graph_epoch != v.config_epoch:
+            self._capture()
+        if self._graph is not None:
+            with torch.cuda.stream(self._stream):
+                self._graph.replay()
+        else:
+            self._issue_step()
+        self._stream.synchronize()
+
+    def _read_back(self):
+        """After work issued through the VecGridWorld on the current stream (task upload, reset)."""
+        self._stream.wait_stream(torch.cuda.current_stream(self._vec.device))
+        if self._hip.hipMemcpyAsync(self._pin.data_ptr(), self._vec.host_view.data_ptr(), self._pin.numel(), _HIP_D2H,
+                                    C.c_void_p(self._stream.cuda_stream)):
+            raise L.IgwError('hipMemcpyAsync (read-back) failed')
+        self._stream.synchronize()
 
     @property
     def unwrapped(self):
         return self
+
+    # -- the reference's public attributes (env.py:32-38), read-only views of the device state ----------------------
+    @property
+    def step_no(self):
+        return int(self._host['agent'][60:62].view(np.uint16)[0])
+
+    @property
+    def grid(self):
+        """int32 [9, 11, 11] copy of the world grid as of the last reset / step (GridWorld.grid, env.py:34)."""
+        return self._host['grid'].reshape(9, 11, 11).astype(np.int32)
 
     # -- tasks (env.py:155-204) --
     def set_task(self, task):
@@ -83,11 +274,11 @@ class GridWorld:
             warnings.warn('The .set_task method has no effect with an initialized tasks generator. '
                           'Drop it using .set_tasks_generator(None) after calling .set_task')
         self._task = task
-        self._reset(keep_size=True)  # GridWorld.reset, not SizeReward.reset
+        self.reset()
 
     def set_task_generator(self, task_generator):
         self._task_generator = task_generator
-        self._reset(keep_size=True)
+        self.reset()
 
     def initialize_world(self, starting_grid, initial_poisition):
         self._overwrite_starting_grid = starting_grid
@@ -95,13 +286,13 @@ class GridWorld:
                       'Use .deinitialize_world to restore the original state.')
         self.initial_position = tuple(initial_poisition[:3])
         self.initial_rotation = tuple(initial_poisition[3:])
-        self._reset(keep_size=True)
+        self.reset()
 
     def deinitialize_world(self):
         self._overwrite_starting_grid = None
         self.initial_position = (0, 0, 0)
         self.initial_rotation = (0, 0)
-        self._reset(keep_size=True)
+        self.reset()
 
     @property
     def task(self):
@@ -122,7 +313,7 @@ class GridWorld:
                             None if getattr(t, 'full_grid', None) is None else np.asarray(t.full_grid)[None],
                             invariant=getattr(t, 'invariant', True), init_pose=pose)
 
-    def _reset(self, keep_size):
+    def reset(self):
         if self._task is None:
             if self._task_generator is None:
                 raise ValueError(_NO_TASK)
@@ -131,32 +322,27 @@ class GridWorld:
             self._task = self._task_generator.reset()
         self._task.reset()
         self._upload_task()
-        self._vec.reset(keep_size=keep_size)
+        self._vec.reset()
+        # GridWorld.max_int (env.py:241): the user task -- full_grid admissibility included -- on the starting grid
+        meta = self._vec.task_meta[0, 42:44]
+        self._read_back()
+        self.max_int = int(meta.cpu().numpy().view(np.int16)[0])
         obs = self._obs()
         self._counters = self._read_counters()
-        # GridWorld.max_int (env.py:241): the user task -- full_grid admissibility included -- on the starting grid
-        self.max_int = int(self._vec.task_meta[0, 42:44].cpu().numpy().view(np.int16)[0])
-        self.prev_grid_size = int(np.count_nonzero(obs['grid'])) if self.vector_state else \
-            int(np.count_nonzero(self._vec.grid[0].cpu().numpy()))   # env.py:242
+        self.prev_grid_size = int(np.count_nonzero(self._host['grid']))   # env.py:242
         return obs
 
-    def reset(self):
-        return self._reset(keep_size=False)
-
     def _read_counters(self):
-        """(max_int, prev_grid_size of the synthetic task, SizeReward.size): the integers the reward is made of."""
-        st = self._vec.task_state()
-        return int(st['max_int'][0]), int(st['prev_size'][0]), int(st['size'][0])
+        """(max_int, prev_grid_size) of the synthetic task: the integers the reward is made of."""
+        a = self._aux_i16
+        return int(a[2]), int(a[1]) & 0x7fff
 
     def _obs(self):
-        v = self._vec
-        torch.cuda.synchronize(v.device)
-        obs = {'inventory': v.inventory[0].cpu().numpy().astype(np.float32),
-               'compass': v.compass.cpu().numpy().astype(np.float32),
-               'dialog': self._task.chat}
+        f = self._out_f32
+        obs = {'inventory': f[5:11].copy(), 'compass': f[11:12].copy(), 'dialog': self._task.chat}
         if self.vector_state:
-            obs['grid'] = v.grid[0].cpu().numpy().astype(np.int32)
-            obs['agentPos'] = v.agent_pos[0].cpu().numpy().astype(np.float32)
+            obs['grid'] = self._host['grid'].reshape(9, 11, 11).astype(np.int32)
+            obs['agentPos'] = f[0:5].copy()
         if self.target_in_obs:
             obs['target_grid'] = np.asarray(self._task.target_grid).copy().astype(np.int32)
         if self.do_render:
@@ -168,43 +354,108 @@ class GridWorld:
             if self._task_generator is None:
                 raise ValueError(_NO_TASK)
             raise ValueError('Task is not initialized! Run .reset() first.')
+        A = self._act
         if self.action_space_type == 'flying':
             inv = int(action['inventory'])
             if inv < 0 or inv > 6:
                 raise ValueError(f'Bad inventory id: {inv}')  # core/world.py:354-355
-            a = {'movement': np.asarray(action['movement'], np.float32)[None],
-                 'camera': np.asarray(action['camera'], np.float32)[None],
-                 'inventory': np.array([inv], np.int32), 'placement': np.array([int(action['placement'])], np.int32)}
+            cam = np.asarray(action['camera'], np.float32)
+            VecGridWorld._check_camera(cam)
+            A['movement'][:] = np.asarray(action['movement'], np.float32)
+            A['camera'][:] = cam
+            A['inventory'][0] = inv
+            A['placement'][0] = int(action['placement'])
         elif not self.discretize:
             hot = int(action['hotbar'])
             if hot < 0 or hot > 6:
                 raise ValueError(f'Bad inventory id: {hot}')
-            b = [int(bool(action[k])) for k in ('forward', 'back', 'left', 'right', 'jump', 'attack', 'use')] + [hot]
-            a = {'buttons': np.array([b], np.uint8), 'camera': np.asarray(action['camera'], np.float32)[None]}
+            cam = np.asarray(action['camera'], np.float32)
+            VecGridWorld._check_camera(cam)
+            A['buttons'][:7] = [int(bool(action[k])) for k in ('forward', 'back', 'left', 'right', 'jump', 'attack', 'use')]
+            A['buttons'][7] = hot
+            A['camera'][:] = cam
         else:
-            a = torch.tensor([int(action)], dtype=torch.int32)
-        self._vec.step(a)
+            A['walk'][0] = int(action)
+        self._device_step()
         obs = self._obs()
         # The reward as the reference's Python value: rebuilt from the device's integer counters with the
         # reference's own expression, so -1 * 0.1 is the double -0.1 (the device's float32 copy is only a
         # convenience for tensor consumers) and right * 1 stays an int.
-        mi0, sz0, size0 = self._counters
-        self._counters = mi1, sz1, size1 = self._read_counters()
-        self.right_placement, self.wrong_placement = right, wrong = mi1 - mi0, sz0 - sz1   # task.py:108-116
+        # (locals, as in the reference: GridWorld.right_placement / wrong_placement themselves are never updated by
+        # step -- env.py:291 -- which is why SizeReward's penalty term is always 0)
+        mi0, sz0 = self._counters
+        self._counters = mi1, sz1 = self._read_counters()
+        right, wrong = mi1 - mi0, sz0 - sz1                                                   # task.py:108-116
         if right == 0:
             reward = wrong * self.wrong_placement_scale                                       # env.py:293-296
         else:
             reward = right * self.right_placement_scale
-        if self.size_reward:   # SizeReward.step (env.py:325-331); GridWorld.wrong_placement stays 0 there (F6)
-            reward = (size1 - size0) + min(0 * 0.02, 0)
-        return obs, reward, bool(self._vec.done[0].item()), {}
+        return obs, reward, bool(self._host['out'][52]), {}
 
     def render(self):
         raise ValueError('create env with render=True')
 
 
-def create_env(**kwargs):
-    return GridWorld(**kwargs)
+class Wrapper:
+    """gridworld/env.py:306-314: attribute pass-through to the wrapped env."""
+
+    def __init__(self, env):
+        self.env = env
+        self.action_space = env.action_space
+        self.observation_space = env.observation_space
+
+    def __getattr__(self, name):
+        if name == 'env':
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+    def reset(self):
+        return self.env.reset()
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def render(self, mode='human', **kwargs):
+        return self.env.render()
+
+
+class SizeReward(Wrapper):
+    """gridworld/env.py:316-331, literally: the reward is the growth of max(GridWorld.max_int, size) -- and
+    GridWorld.max_int is only evaluated at reset (env.py:241), so it is non-zero on the first step of an episode
+    that starts with part of the target built -- plus min(GridWorld.wrong_placement * 0.02, 0), which is 0.0."""
+
+    def __init__(self, env):
+        super().__init__(env)
+        self.size = 0
+
+    def reset(self):
+        self.size = 0
+        return super().reset()
+
+    def step(self, action):
+        obs, reward, done, info = super().step(action)
+        intersection = self.unwrapped.max_int
+        reward = max(intersection, self.size) - self.size
+        self.size = max(intersection, self.size)
+        reward += min(self.unwrapped.wrong_placement * 0.02, 0)
+        return obs, reward, done, info
+
+
+def create_env(render=True, discretize=True, size_reward=True, select_and_place=True, right_placement_scale=1,
+               render_size=(64, 64), target_in_obs=False, vector_state=False, max_steps=250, action_space='walking',
+               wrong_placement_scale=0.1, name='', fake=False, device='cuda:0'):
+    """gridworld/env.py:333-350 (same defaults)."""
+    env = GridWorld(render=render, select_and_place=select_and_place, discretize=discretize,
+                    right_placement_scale=right_placement_scale, wrong_placement_scale=wrong_placement_scale, name=name,
+                    render_size=render_size, target_in_obs=target_in_obs, vector_state=vector_state, max_steps=max_steps,
+                    action_space=action_space, fake=fake, device=device)
+    if size_reward:
+        env = SizeReward(env)
+    return env
 
 
 _REGISTRY = {'IGLUGridworld-v0': {}, 'IGLUGridworldVector-v0': {'vector_state': True, 'render': False}}
@@ -226,14 +477,28 @@ def make_vec(num_envs, device='cuda:0', **kwargs):
     return VecGridWorld(num_envs, device=device, **kwargs)
 
 
-def _register_with_gym():
-    for modname in ('gymnasium', 'gym'):
-        try:
-            mod = __import__(modname)
-            for env_id, kw in _REGISTRY.items():
-                mod.envs.register(id=env_id, entry_point='gridworld_amd.env:create_env', kwargs=kw)
-        except Exception:
-            pass
+def register(gym_module=None):
+    """Registers 'IGLUGridworld-v0' and 'IGLUGridworldVector-v0' (gridworld/env.py:352-362) with `gym_module` --
+    anything with the classic `envs.register(id=, entry_point=, kwargs=)` -- or, by default, with whichever of
+    gymnasium / gym is importable.  Returns the names of the modules registered with.  An import error of an
+    absent package is the only thing ignored: a registry that rejects the ids raises."""
+    mods = []
+    if gym_module is not None:
+        mods.append(gym_module)
+    else:
+        import importlib
+        for name in ('gymnasium', 'gym'):
+            try:
+                mods.append(importlib.import_module(name))
+            except ImportError:
+                pass
+    for mod in mods:
+        for env_id, kw in _REGISTRY.items():
+            mod.envs.register(id=env_id, entry_point='gridworld_amd.env:create_env', kwargs=dict(kw))
+    return [m.__name__ for m in mods]
 
 
-_register_with_gym()
+try:
+    register()
+except Exception as _e:  # noqa: BLE001 -- a gym that is present but refuses the ids: say so, importing the package still works
+    warnings.warn(f'gridworld_amd: registering the env ids with gym failed: {_e}')

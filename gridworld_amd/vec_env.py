@@ -59,12 +59,17 @@ class VecGridWorld:
         self.autoreset = bool(autoreset)
         N, T, dev = self.num_envs, self.num_tasks, self.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
-        self.grid_buf = z((N, L.GRID_STRIDE), torch.int8)
+        # What a host-side consumer reads back after a step -- output, agent and aux records, the grid -- comes from ONE
+        # allocation (`host_view`), so the 1-env facade moves it with a single device-to-host copy (gridworld_amd/env.py)
+        rec = L.OUT_BYTES + L.AGENT_BYTES + L.AUX_BYTES
+        self.host_view = z((N * (rec + L.GRID_STRIDE),), torch.uint8)
+        cut = lambda lo, width: self.host_view[N * lo:N * (lo + width)].view(N, width)  # noqa: E731
+        self.out_buf = cut(0, L.OUT_BYTES)         # agentPos, inventory, compass, reward, done of every step
+        self.agent_buf = cut(L.OUT_BYTES, L.AGENT_BYTES)   # pose, inventory, step_no, pack (include/igw.h)
+        self.aux_buf = cut(L.OUT_BYTES + L.AGENT_BYTES, L.AUX_BYTES)   # size, prev_size, max_int, target_size, task, episode
+        self.grid_buf = cut(rec, L.GRID_STRIDE).view(torch.int8)
         self.occ_buf = z((N, L.OCC_WORDS), torch.int32)
         self.hist_buf = z((N, L.HIST_ROW), torch.int16)
-        self.agent_buf = z((N, L.AGENT_BYTES), torch.uint8)   # pose, inventory, step_no, pack (include/igw.h)
-        self.aux_buf = z((N, L.AUX_BYTES), torch.uint8)       # size, prev_size, max_int, target_size, task, episode
-        self.out_buf = z((N, L.OUT_BYTES), torch.uint8)       # agentPos, inventory, compass, reward, done of every step
         self.task_target = z((T, L.GRID_STRIDE), torch.int8)
         self.task_start = z((T, L.GRID_STRIDE), torch.int8)
         self.task_start_occ = z((T, L.OCC_WORDS), torch.int32)
@@ -93,6 +98,9 @@ class VecGridWorld:
         self._sampling = None        # (seed,) / ('random', kwargs) of the device-side generator, for sub-batches
         self._traj = None
         self._children = []
+        # bumped by every call that changes what a step LAUNCH is given by value (the kernel parameters: sampler
+        # settings, the episode-log buffers): a captured StepGraph carries the values of its capture
+        self.config_epoch = 0
 
     def __del__(self):
         ctx = getattr(self, 'ctx', None)
@@ -102,7 +110,11 @@ class VecGridWorld:
 
     def _make_views(self):
         """The observation / result tensors of the env protocol (env.py:281-303) and the per-env task row / episode
-        counter as strided VIEWS of the records the kernels read and write (include/igw.h): nothing is copied."""
+        counter as strided VIEWS of the records the kernels read and write (include/igw.h): nothing is copied.
+        They are NOT dense [N] tensors: agent_pos [N,5], inventory [N,6], compass [N], reward [N] are float32 views
+        with a row stride of 16 elements (the 64-byte output record), done [N] is uint8 with stride 64, env_task /
+        episode int32 with stride 4, grid [N,9,11,11] int8 with row stride 1104.  A consumer that needs packed
+        memory (.view(), DLPack, a custom kernel indexing [i]) takes `dense()` or calls .contiguous()."""
         N = self.num_envs
         f = self.out_buf.view(torch.float32)          # [N, 16]
         self.agent_pos = f[:, 0:5]                    # x, y, z, pitch, yaw
@@ -184,6 +196,7 @@ class VecGridWorld:
             raise ValueError('set_task_sampling needs filled task rows: call set_tasks first')
         L.check(self.lib.igw_set_task_sampling(self.ctx, int(bool(enabled)), int(seed), n), 'igw_set_task_sampling')
         self._sampling = ('table', int(seed), n) if enabled else None
+        self.config_epoch += 1
         for c in self._children:
             c._inherit_sampling()
 
@@ -197,6 +210,7 @@ class VecGridWorld:
                                               kw['height_levels'], kw['max_dist'], kw['num_colors'], self._stream()),
                 'igw_set_random_tasks')
         self._sampling = ('random', int(seed), kw) if enabled else None
+        self.config_epoch += 1
         if enabled:
             self._have_tasks = True
             self._tasks_filled = max(self._tasks_filled, self.num_envs)
@@ -219,11 +233,13 @@ class VecGridWorld:
         L.check(self.lib.igw_set_trajectory_log(self.ctx, rec.data_ptr(), heads.data_ptr(), n_envs, cap),
                 'igw_set_trajectory_log')
         self._traj = (rec, heads, n_envs, cap)
+        self.config_epoch += 1
         return rec, heads
 
     def disable_trajectory_log(self):
         L.check(self.lib.igw_set_trajectory_log(self.ctx, None, None, 0, 0), 'igw_set_trajectory_log')
         self._traj = None
+        self.config_epoch += 1
 
     _STATE_KEYS = ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'aux_buf', 'out_buf', 'task_target', 'task_start',
                    'task_start_occ', 'task_meta', 'task_index', 'stats_buf')
@@ -259,6 +275,12 @@ class VecGridWorld:
     def obs(self):
         return self._obs.copy()
 
+    def dense(self):
+        """Packed COPIES of the per-step results for consumers that cannot take strided views (see _make_views):
+        dict(agentPos [N,5], inventory [N,6], compass [N], reward [N], done [N] uint8), each contiguous."""
+        return {'agentPos': self.agent_pos.contiguous(), 'inventory': self.inventory.contiguous(),
+                'compass': self.compass.contiguous(), 'reward': self.reward.contiguous(), 'done': self.done.contiguous()}
+
     def reset(self, mask=None, keep_size=False):
         self._need_tasks()
         m = None
@@ -288,7 +310,8 @@ class VecGridWorld:
         """walking: int32 tensor [N]; walking with discretize=False: dict(buttons u8[N,8] = forward, back,
         left, right, jump, attack, use, hotbar -- or those eight keys separately -- and camera f32[N,2]);
         flying: dict(movement f32[N,3], camera f32[N,2], inventory i32[N], placement i32[N]).
-        Returns (obs, reward, done, info) of tensors living in HBM -- views of the kernels' output record, the same
+        Returns (obs, reward, done, info) of tensors living in HBM -- STRIDED views of the kernels' 64-byte output
+        record (reward: float32, stride 16 elements; done: uint8, stride 64; see _make_views / dense()), the same
         tensors every call.  Actions that already are contiguous device tensors of the kernel's dtypes (walking: int32
         [N]; flying: float32 / int32) go straight to the C ABI: no conversion, no copy, one ctypes call."""
         if not self._have_tasks:
@@ -346,9 +369,12 @@ class VecGridWorld:
         device tensor [T, N]; flying dict of device tensors movement f32[T,N,3], camera f32[T,N,2], inventory i32[T,N],
         placement i32[T,N]; walking Dict: buttons u8[T,N,8], camera f32[T,N,2].  The graph reads the action BUFFERS at
         replay time: refill them in place (copy_) between replays to step with new actions.  record=True also copies
-        every step's output record (StepGraph.outs uint8 [T, N, 64]; .rewards / .dones are views of it).  Everything
-        that varies between replays lives in device memory (include/igw.h), so the samplers, auto-resets and the
-        episode log advance inside the replayed graph exactly as they do eagerly."""
+        every step's output record (StepGraph.outs uint8 [T, N, 64]; .rewards / .dones are views of it).  What varies
+        between replays -- actions, env state, task table, the samplers' episode counters, the log's heads -- lives in
+        device memory (include/igw.h), so samplers, auto-resets and the episode log advance inside the replayed graph
+        exactly as they do eagerly.  What does NOT: the sampler SETTINGS and the episode-log buffers are kernel
+        parameters, frozen at capture; after set_task_sampling / set_random_tasks / enable_ / disable_trajectory_log
+        replay() raises (capture again)."""
         self._need_tasks()
         return StepGraph(self, actions, record)
 
@@ -434,13 +460,14 @@ class VecGridWorld:
 
     # ---- introspection ----
     def stats(self):
-        """Device counters of this env and of its sub-batches (VecGridWorld.split)."""
+        """Device counters of this env and of its sub-batches (VecGridWorld.split).  `steps`: env-steps executed, counted
+        on the device by every step launch and fused rollout (`rollout_steps` is the same counter's old name)."""
         s = self.stats_buf.sum(0)
         for c in self._children:
             s = s + c.stats_buf.sum(0)
         s = s.cpu()
         return {'changed': int(s[L.STAT_CHANGED]), 'resets': int(s[L.STAT_RESETS]),
-                'rollout_steps': int(s[L.STAT_STEPS]), 'rescans': int(s[L.STAT_RESCANS]),
+                'steps': int(s[L.STAT_STEPS]), 'rollout_steps': int(s[L.STAT_STEPS]), 'rescans': int(s[L.STAT_RESCANS]),
                 'bad_poses': int(s[L.STAT_BAD_POSE]), 'bad_actions': int(s[L.STAT_BAD_ACTION]),
                 'bad_tasks': int(s[L.STAT_BAD_TASK])}
 
@@ -475,6 +502,12 @@ class StepGraph:
     def __init__(self, env, actions, record):
         self.env = env
         dev, N = env.device, env.num_envs
+        # A launch is given the kernel parameters BY VALUE: the graph freezes the sampler settings (set_task_sampling,
+        # set_random_tasks) and the episode-log buffers (enable / disable_trajectory_log) of the moment of capture.
+        # replay() refuses to run after any of them changed (config_epoch), and the graph keeps the log's buffers
+        # alive, so a stale graph can neither run a stale configuration silently nor write into freed memory.
+        self.config_epoch = env.config_epoch
+        self._held = env._traj
 
         def need(x, dt, shape, what):
             if not (type(x) is torch.Tensor and x.is_cuda and x.dtype is dt and x.is_contiguous() and tuple(x.shape[1:]) == shape):
@@ -511,8 +544,12 @@ class StepGraph:
             self.rewards, self.dones = f[:, :, 12], self.outs[:, :, 52]
 
     def replay(self):
-        self.graph.replay()
         env = self.env
+        if env.config_epoch != self.config_epoch:
+            raise L.IgwError('StepGraph is stale: set_task_sampling / set_random_tasks / enable_trajectory_log / '
+                             'disable_trajectory_log was called after capture_steps (a captured launch carries those '
+                             'settings by value); capture the steps again')
+        self.graph.replay()
         return env._obs.copy(), env.reward, env.done, {}
 
 

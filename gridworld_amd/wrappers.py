@@ -1,27 +1,6 @@
 """Wrappers of the reference that sit on the step path (gridworld/wrappers.py)."""
 from . import spaces
-
-
-class Wrapper:
-    """Attribute pass-through to the wrapped env (gridworld/env.py:306-314)."""
-
-    def __init__(self, env):
-        self.env = env
-
-    def __getattr__(self, name):
-        if name == 'env':
-            raise AttributeError(name)
-        return getattr(self.env, name)
-
-    @property
-    def unwrapped(self):
-        return self.env.unwrapped
-
-    def reset(self):
-        return self.env.reset()
-
-    def step(self, action):
-        return self.env.step(action)
+from .env import Wrapper  # noqa: F401  (gridworld/env.py:306-314; re-exported: the reference imports gym.Wrapper here)
 
 
 class Actions(Wrapper):
@@ -48,7 +27,13 @@ class EpisodeLogger:
 
     Arrays per file (T = steps of the episode): agentPos f32[T+1,5], inventory f32[T+1,6], compass f32[T+1,1],
     grid int32[T+1,9,11,11] (rebuilt from the starting grid and the logged one-cell changes), reward f64[T],
-    done bool[T], plus `task` (row of the task table), `env`, `episode`.  Entry 0 is the reset observation."""
+    done bool[T], plus `task` (row of the task table), `env`, `episode`.  Entry 0 is the reset observation.
+
+    `actions` are the actions AS EXECUTED, not the raw inputs the reference's Logged appends (wrappers.py:98): the
+    device record packs a flying action's inventory into 3 bits and its placement into 2 (include/igw.h), so an
+    inventory id the kernel rejected (outside 0..6: run as 0 and counted in stats()['bad_actions']) is logged as 0 and
+    a placement other than 1 / 2 as 0.  Replaying a log therefore reproduces the trajectory, not the bad-action
+    counts; Discrete(18) ids, movement / camera floats and Dict buttons are logged raw."""
 
     def __init__(self, vec, n_envs=1, path='episodes', desc='', glob_step=0, capacity=None):
         import numpy as np

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IGW_VERSION 4
+#define IGW_VERSION 5
 /* igw_config.lanes_per_env == 0 picks the group width measured fastest on an MI355X for the batch size
  * (profiles/r02_sweep_lanes*.txt): 32 lanes per env up to IGW_AUTO_32_MAX envs, 16 up to IGW_AUTO_16_MAX, 8 up to
  * IGW_AUTO_8_MAX, 4 beyond (a launch then has between about 512 and 4,096 wavefronts for 1,024 SIMDs).  64 (one
@@ -78,7 +78,8 @@ extern "C" {
 #define IGW_STAT_STRIPES 64
 #define IGW_STAT_CHANGED 0 /* env-steps whose block count changed (max_intersection recomputed) */
 #define IGW_STAT_RESETS 1  /* auto-resets performed */
-#define IGW_STAT_STEPS 2   /* env-steps executed by igw_rollout_walking */
+#define IGW_STAT_STEPS 2   /* env-steps executed: every step launch adds its envs (once per block), the fused
+                            * rollouts add T per env -- the device-side count of the work done */
 #define IGW_STAT_RESCANS 3 /* histogram row updates (env-steps that changed a cell; each takes the row maximum) */
 #define IGW_STAT_BAD_POSE 4   /* task rows whose init_pose was rejected (non-finite, |x| or |z| > 10, |y| > 64,
                                * |yaw| or |pitch| > 1e6) and replaced by the default pose */
@@ -191,6 +192,10 @@ typedef struct igw_buffers {
 typedef struct igw_ctx igw_ctx;
 
 int igw_version(void);
+/* Identity of the kernel build: a hash of the sources the library was compiled from (csrc/ + this header + the
+ * compiler flags; gridworld_amd/build.py: source_hash).  Profiles under profiles/ carry the id of the library they
+ * were taken with; bench.py marks a profile of another build as stale. */
+const char* igw_build_id(void);
 const char* igw_last_error(void);
 /* number of visible HIP devices (0 if none / runtime unusable); does not create a context */
 int igw_device_count(void);

@@ -23,7 +23,10 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f'{name} declared in include/igw.h but not exported'
     assert sorted(_lib.EXPORTS) == declared
-    assert L.igw_version() == _lib.VERSION == 4
+    assert L.igw_version() == _lib.VERSION == 5
+    # the library is stamped with the hash of the sources it was built from (bench.py compares profiles with it)
+    from gridworld_amd import build as B
+    assert _lib.build_id() == B.source_hash() == B.built_id()
 
 
 def test_layout_constants_match_header():

@@ -25,7 +25,7 @@ acts = env.fill_actions(8, seed=3)
 for t in range(8):
     env.step(acts[t])
 torch.cuda.synchronize()
-steps = env.num_envs * 8 + int(env.stats()['bad_actions'])
+steps = int(env.stats()["steps"])   # the device-side counter (IGW_STAT_STEPS)
 vals, how = gd.gather_counts_rccl(steps, dev)
 floats = gd.gather_floats(1.5)
 gd.barrier()
@@ -43,3 +43,30 @@ def test_rccl_gather_single_rank_group():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('RESULT')][-1]
     assert line.startswith('RESULT 32768 [32768] rccl all_gather of one int64 per rank [1.5]'), line
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_torchrun_on_one_shared_gpu():
+    """The N > 1 CONTROL PLANE on a 1-GPU box: `bench.py --gpus 2` starts its two ranks through
+    `python -m torch.distributed.run` (child processes, started before anything touches the GPU) and IGW_SHARE_GPU=1
+    puts both on cuda:0.  Checked: rendezvous, the shared-memory barrier of the timing bracket, the per-window max over
+    ranks, the gather of every rank's DEVICE-SIDE step counter (IGW_STAT_STEPS delta of the window) with `value`
+    computed from their sum, a clean exit of both ranks.  RCCL refuses two ranks on one device, so the gather takes the
+    agreed gloo fallback here (on a real node it is RCCL over xGMI; the one-rank RCCL gather is the test above).
+    NO scaling number can be read from this: both ranks share one GPU."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', IGW_SHARE_GPU='1', IGW_RCCL_TIMEOUT_S='30')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    n, k = 8192, 20
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', str(k), '--warmup', '5', '--envs-per-gpu', str(n),
+           '--windows', '3', '--rehearsals', '1', '--no-cpu-baseline', '--no-secondary', '--no-api', '--no-fused', '--no-async']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    cfg = line['config']
+    assert line['n_gpus'] == 2 and cfg['ranks_seen'] == [0, 1] and cfg['total_envs'] == 2 * n
+    assert cfg['device_step_counts_per_rank'] == [n * k, n * k]          # what the kernels of each rank counted
+    assert abs(line['value'] - 2 * n * k / (line['ms_per_step'] * 1e-3 * k)) < 1e-6 * line['value']
+    assert 'rccl' in cfg['step_count_gather'] or 'gloo' in cfg['step_count_gather']
+    assert len(cfg['kernel_us_per_rank']) == 2 and line['scaling'] == 'weak'

@@ -190,3 +190,52 @@ def test_actions_wrapper():
         o2, r2, d2, _ = ref.step(a)
         assert r1 == r2 and d1 == d2 and np.array_equal(o1['agentPos'], o2['agentPos'])
     assert env.unwrapped is env.env and env.max_steps == ref.max_steps
+
+
+def test_public_attribute_surface_of_the_reference_env():
+    """GridWorld's public attributes (gridworld/env.py:32-38) and the wrapper structure (env.py:306-331): `unwrapped`
+    is the GridWorld inside SizeReward; step_no, grid, agent.{position, rotation, dy, time_int_steps, active_block,
+    inventory} and world.placed follow the device state step by step (float64 internals of the fixture, bit for
+    bit); the reference's own Logged wrapper reads unwrapped.step_no (wrappers.py:99)."""
+    import gridworld_amd as G
+    fx = GR.load_fixture('s2_walk_cdm_sizereward')
+    e = 2
+    env = G.make('IGLUGridworld-v0', vector_state=True, render=False, **fx['kwargs'])
+    assert isinstance(env, G.SizeReward) and isinstance(env.unwrapped, G.GridWorld) and env.unwrapped is env.env
+    assert env.unwrapped.unwrapped is env.unwrapped and env.size == 0
+    inner = env.unwrapped
+    assert inner.agent.inventory == [20] * 6 and inner.agent.active_block == 1 and inner.agent.time_int_steps == 2
+    assert inner.step_no == 0 and inner.grid.shape == (9, 11, 11) and inner.grid.dtype == np.int32 and not inner.grid.any()
+    env.set_task(G.Task('', fx['targets'][e].astype(np.int32), starting_grid=_sparse(fx['starts'][e])))
+    obs = env.reset()
+    assert np.array_equal(inner.grid, obs['grid']) and inner.step_no == 0 and env.max_steps == fx['kwargs']['max_steps']
+    assert inner.agent.position == (0.0, 0.0, 0.0) and inner.agent.rotation == (0.0, 0.0)
+    assert inner.world.placed == {(int(x) - 5, int(y) - 1, int(z) - 5) for y, x, z in zip(*np.nonzero(obs['grid']))}
+    w = inner.world.world
+    assert w[(0, -2, 0)] == -1 and w[(18, -2, -18)] == 0 and len(w) == 37 * 37 + len(inner.world.placed)
+    steps = 0
+    for t in range(120):
+        if fx['reset_before'][e, t]:
+            env.reset()
+            steps = 0
+            assert env.size == 0
+        obs, reward, done, _ = env.step(int(fx['actions'][e, t]))
+        steps += 1
+        it = fx['internal'][e, t]
+        a = inner.agent
+        got = np.array([*a.position, *a.rotation, a.dy, a.time_int_steps, a.active_block], np.float64)
+        assert np.array_equal(got.view(np.uint64), it.view(np.uint64)), t
+        assert inner.step_no == steps and np.array_equal(inner.grid, obs['grid'])
+        assert a.inventory == [int(v) for v in obs['inventory']] and reward == fx['reward'][e, t]
+        assert env.size == max(env.size, inner.max_int)
+    # set_task goes to GridWorld.reset through the wrapper's attribute pass-through: SizeReward.size survives it
+    # (env.py:155-166 vs 321-323), reset() through the wrapper clears it
+    env.size = 7
+    env.set_task(G.Task('', fx['targets'][e].astype(np.int32), starting_grid=[]))
+    assert env.size == 7
+    env.reset()
+    assert env.size == 0
+    # GridWorld's own constructor defaults differ from create_env's (env.py:27-31 vs 333-338)
+    raw = G.GridWorld(render=False)
+    assert raw.select_and_place is False and raw.discretize is False and raw.vector_state is True
+    assert set(raw.action_space.keys()) == {'forward', 'back', 'left', 'right', 'jump', 'attack', 'use', 'camera', 'hotbar'}

@@ -150,66 +150,31 @@ def test_walking_off_lattice_pose_uses_general_trig():
 
 
 def test_flying_divergence_from_glibc_reference_at_scale(capsys):
-    """A-fly residual, quantified: BASELINE configs[3] -- 65,536 flying envs x 250 steps,
-    rt20 targets, uniform random actions -- on the HIP path (correctly rounded trig) against the oracle with
-    GLIBC trig (what the Python reference calls) on a 4,096-env sample.  glibc is off by one ulp on ~0.1 % of its
-    sin / cos results; such a difference changes an output only when it flips a rounding: the float32 cast of an
-    observation, or -- far rarer -- normalize() of a ray sample or a collision test, which then changes grid /
-    inventory / reward.  The counts are printed (and recorded in gpurun_out/afly_divergence.json) and bounded."""
+    """A-fly residual, quantified against GLIBC and not against the product's own trig: BASELINE configs[3] -- ALL
+    65,536 flying envs x full 250-step episodes, rt20 targets, uniform random actions -- on the HIP path (correctly
+    rounded trig) against the oracle with glibc trig (what the Python reference calls), every env, every step
+    (tests/afly_divergence.py).  glibc is off by one ulp on ~0.1 % of its sin / cos results; such a difference changes
+    an output only when it flips a rounding: the float32 cast of an observation, or -- far rarer -- normalize() of a
+    ray sample or a collision test, which then changes grid / inventory / reward.  The counts are printed, recorded in
+    gpurun_out/afly_divergence_test.json and bounded; the >= 1e8-step run is profiles/r05_afly_divergence.json."""
     import json
     import os
-    from gridworld_amd import VecGridWorld, workloads
-    from oracle import oracle as O
-    N, S, T = 65536, 4096, 250
-    kw = dict(size_reward=False, action_space='flying', max_steps=T)
-    tg = workloads.rt20(N, seed=404)
-    env = VecGridWorld(N, autoreset=False, **kw)
-    env.set_tasks(tg.to(env.device))
-    env.reset()
-    ob = O.OracleBatch(S, **kw)          # default trig mode: libm
-    ob.set_tasks(tg[:S].numpy())
-    ob.reset()
-    g = torch.Generator(device=env.device)
-    g.manual_seed(4)
-    first_int = np.full(S, -1)           # first step at which grid / inventory / reward / done differ
-    first_f32 = np.full(S, -1)           # first step at which agentPos / compass (float32) differ
-    cores = len(os.sched_getaffinity(0))
-    for t in range(T):
-        a = dict(movement=torch.rand((N, 3), generator=g, device=env.device) * 2 - 1,
-                 camera=torch.rand((N, 2), generator=g, device=env.device) * 10 - 5,
-                 inventory=torch.randint(0, 7, (N,), generator=g, device=env.device, dtype=torch.int32),
-                 placement=torch.randint(0, 3, (N,), generator=g, device=env.device, dtype=torch.int32))
-        env.step(a)
-        ob.step_flying(a['movement'][:S].cpu().numpy(), a['camera'][:S].cpu().numpy(), a['inventory'][:S].cpu().numpy(),
-                       a['placement'][:S].cpu().numpy(), nthreads=cores)
-        d_int = (env.done[:S].cpu().numpy() != ob.done) | (env.reward[:S].cpu().numpy() != ob.reward) | \
-            (env.inventory[:S].cpu().numpy() != ob.inventory).any(-1)
-        if t % 10 == 9 or t == T - 1:
-            d_int |= (env.grid[:S].cpu().numpy().reshape(S, -1) != ob.grid).any(-1)
-        d_f32 = (env.agent_pos[:S].cpu().numpy().view(np.uint32) != ob.agentPos.view(np.uint32)).any(-1) | \
-            (env.compass[:S].cpu().numpy().view(np.uint32) != ob.compass.view(np.uint32))
-        first_int[(first_int < 0) & d_int] = t
-        first_f32[(first_f32 < 0) & d_f32] = t
-    fin = env.internals()[:S]
-    ref = ob.internals()
-    last_bit = int((fin.view(np.uint64) != ref.view(np.uint64)).any(-1).sum())
-    max_dev = float(np.abs(fin[:, :6] - ref[:, :6]).max())
-    res = dict(envs_compared=S, steps=T, envs_with_integer_divergence=int((first_int >= 0).sum()),
-               envs_with_float32_obs_divergence=int((first_f32 >= 0).sum()),
-               first_integer_divergence_step=None if (first_int < 0).all() else int(first_int[first_int >= 0].min()),
-               first_float32_divergence_step=None if (first_f32 < 0).all() else int(first_f32[first_f32 >= 0].min()),
-               envs_ending_with_a_float64_difference=last_bit, max_abs_float64_deviation=max_dev,
-               env_steps_compared=S * T, total_envs_stepped_on_gpu=N)
+    import afly_divergence as AD
+    res, _ = AD.one_pass(65536, 250, seed=404)
     os.makedirs('gpurun_out', exist_ok=True)
-    with open('gpurun_out/afly_divergence.json', 'w') as f:
+    with open('gpurun_out/afly_divergence_test.json', 'w') as f:
         json.dump(res, f, indent=1)
     with capsys.disabled():
         print('\nA-fly divergence vs glibc reference:', json.dumps(res))
+    N = res['envs']
+    assert res['env_steps'] == 65536 * 250
     # every env of the full batch finished its episode and the invariants of the domain hold
-    assert bool(env.done.all()) and int(env.inventory.min()) >= 0
-    assert res['envs_with_integer_divergence'] <= S // 100      # < 1 % of episodes see any integer-output change
-    assert res['envs_with_float32_obs_divergence'] <= S // 10   # float32 observations: < 10 % of episodes, last bit
-    assert max_dev < 1e-6 or res['envs_with_integer_divergence'] > 0
+    assert res['all_done'] and res['min_inventory'] >= 0
+    # integer outputs: a handful of episodes per 16 M env-steps at most; float32 observations: last-bit flips in < 1 %
+    # of the episodes; the float64 trajectories themselves part in the last bits of a few per cent of the episodes
+    assert res['envs_with_integer_divergence'] <= N // 2000
+    assert res['envs_with_float32_obs_divergence'] <= N // 100
+    assert res['max_abs_float64_deviation_of_clean_envs'] < 1e-9
 
 
 @pytest.mark.parametrize('autoreset', [True, False])

@@ -1,0 +1,67 @@
+"""gym registration of the two env ids (gridworld/env.py:352-362).  Neither gym nor gymnasium is installed in this
+image, so the registry is the class-shell `gym` of tests/golden/shims (the one the reference itself is imported
+through): gridworld_amd.env.register(gym) must put both ids there with the reference's kwargs, and gym.make must
+build the env through the registered entry point."""
+import importlib
+import os
+import sys
+
+import pytest
+
+SHIMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'shims')
+
+
+@pytest.fixture
+def shim_gym():
+    sys.path.insert(0, SHIMS)
+    for m in [m for m in sys.modules if m == 'gym' or m.startswith('gym.')]:
+        del sys.modules[m]
+    gym = importlib.import_module('gym')
+    assert gym.__file__.startswith(SHIMS)
+    gym.envs.registry.clear()
+    yield gym
+    sys.path.remove(SHIMS)
+    for m in [m for m in sys.modules if m == 'gym' or m.startswith('gym.')]:
+        del sys.modules[m]
+
+
+def test_register_puts_both_ids_into_the_registry(shim_gym):
+    import gridworld_amd.env as E
+    assert E.register(shim_gym) == ['gym']
+    reg = shim_gym.envs.registry
+    assert set(reg) == {'IGLUGridworld-v0', 'IGLUGridworldVector-v0'}
+    assert reg['IGLUGridworld-v0'] == ('gridworld_amd.env:create_env', {})
+    assert reg['IGLUGridworldVector-v0'] == ('gridworld_amd.env:create_env', {'vector_state': True, 'render': False})
+    mod, fn = reg['IGLUGridworld-v0'][0].split(':')
+    assert getattr(importlib.import_module(mod), fn) is E.create_env
+    # with gym importable the default call (what `import gridworld_amd` does) finds it too
+    shim_gym.envs.registry.clear()
+    assert 'gym' in E.register()
+    assert 'IGLUGridworldVector-v0' in shim_gym.envs.registry
+
+    class Refusing:
+        __name__ = 'refusing'
+
+        class envs:
+            @staticmethod
+            def register(**kw):
+                raise RuntimeError('duplicate id')
+    with pytest.raises(RuntimeError):     # a registry that rejects the ids is not swallowed
+        E.register(Refusing)
+
+
+@pytest.mark.gpu
+def test_gym_make_builds_and_steps_the_env(shim_gym):
+    import numpy as np
+    import gridworld_amd as G
+    G.register(shim_gym)
+    env = shim_gym.make('IGLUGridworldVector-v0', size_reward=False)       # the registered kwargs + the caller's
+    assert isinstance(env, G.GridWorld) and env.vector_state and not env.do_render
+    wrapped = shim_gym.make('IGLUGridworld-v0', vector_state=True, render=False)
+    assert isinstance(wrapped, G.SizeReward) and isinstance(wrapped.unwrapped, G.GridWorld)
+    wrapped.set_task(G.dummy_task())
+    obs = wrapped.reset()
+    obs, reward, done, info = wrapped.step(5)
+    assert obs['grid'].shape == (9, 11, 11) and obs['agentPos'].dtype == np.float32 and wrapped.unwrapped.step_no == 1
+    with pytest.raises(NotImplementedError):
+        shim_gym.make('IGLUGridworld-v0')     # render=True default: the renderer is out of scope

@@ -2,9 +2,10 @@
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats, separate PMC passes for HBM traffic and
 # for the SQ issue-side counters.  Raw output lands in gpurun_out/prof_<tag>/ ; tools/summarize_profile.py
 # condenses it into gpurun_out/profiles_<tag>/<tag>_{kernel_stats.csv,traffic.json,issue.json}
-# (copy those into profiles/ to commit them).
+# (copy those into profiles/ to commit them).  Call it as  IGW_GIT_COMMIT=<rev> tools/profile_gpu.sh <tag> "<bench args>":
+# the GPU box has no .git, the summaries are stamped with that commit and with the library's build id.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ARGS=${2:-"--no-cpu-baseline --no-fused --no-async --no-secondary --no-api --windows 3 --rehearsals 1 --steps 200 --warmup 20"}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
