@@ -79,6 +79,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-async', action='store_true', help='skip the secondary two-sub-batch measurement')
     ap.add_argument('--no-secondary', action='store_true', help='skip the flying / cdm secondary windows of the default run')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of one HIP-graph replay')
+    ap.add_argument('--chains', type=int, default=1,
+                    help='capture the timed steps as this many independent chains of sub-batch launches (VecGridWorld.capture_steps(chains=))')
+    ap.add_argument('--chain-sweep', default='2,4', help='also measure these chain counts (config.chain_sweep); empty = none')
     ap.add_argument('--no-api', action='store_true', help='skip the public-API loop measurements (config.api_*)')
     ap.add_argument('--lockstep', action='store_true',
                     help='skip the episode de-synchronisation (round-1 behaviour: all envs at the same episode step)')
@@ -359,6 +362,7 @@ class Runner:
         if not args.lockstep:
             self.busy(0.0, MAX_STEPS)  # at least one episode length
         self.graph, self.head, self.timed_as = None, K, 'eager env.step() calls'
+        self.chains = max(1, int(getattr(args, 'chains', 1)))
         if not args.no_graph and K > 8:
             self._capture()
         self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -409,11 +413,12 @@ class Runner:
         head = min(int(os.environ.get('IGW_BENCH_HEAD', 6)), K - 2)   # (IGW_BENCH_HEAD: experiments only)
         try:
             sub = {k: v[W + head:] for k, v in self.acts.items()} if self.flying else self.acts[W + head:]
-            graph = self.env.capture_steps(sub)
+            graph = self.env.capture_steps(sub, chains=self.chains)
             graph.replay()  # part of the setup: the first launch of a graph also uploads it
             torch.cuda.synchronize(self.device)
             self.graph, self.head = graph, head
-            self.timed_as = f'{head} eager env.step() calls + one replay of VecGridWorld.capture_steps over the other {K - head}'
+            self.timed_as = f'{head} eager env.step() calls + one replay of VecGridWorld.capture_steps over the other {K - head}' + (
+                f' (as {self.chains} independent chains of {self.N // self.chains}-env launches)' if self.chains > 1 else '')
         except Exception as e:  # noqa: BLE001 -- any capture / instantiate failure: eager launches instead
             try:
                 torch.cuda.synchronize(self.device)
@@ -438,7 +443,7 @@ class Runner:
         # the GPU between warm-up and clock
         for t in range(W):
             step(act_t[t])
-        before = env.stats_buf.sum(0)
+        before = env.stats_tensor()
         ev0.record()   # torch creates the HIP events lazily at their first record(): not inside the clock
         ev1.record()
         ev1.query()
@@ -531,7 +536,7 @@ class Runner:
         walls, kernels, ps, resets, cells, counted = [], [], [], [], [], []
         for _ in range(max(1, windows)):
             el, st0_dev, kms, host_tl = self.window()
-            s0, s1 = st0_dev.cpu(), env.stats_buf.sum(0).cpu()
+            s0, s1 = st0_dev.cpu(), env.stats_tensor().cpu()
             walls.append(el)
             kernels.append(kms)
             ps.append(float(s1[L.STAT_CHANGED] - s0[L.STAT_CHANGED]) / (N * K))
@@ -739,6 +744,23 @@ def run(args):
     n_ranks = len(ranks_seen)
     kernel_us_per_rank = [round(x, 3) for x in gdist.gather_floats(1e3 * m['kernel_ms'])]   # (control plane)
     api = r.api_loops() if not args.no_api else None
+    # the same window with the captured steps as P independent chains of sub-batch launches (parallel graph branches)
+    chain_sweep = {}
+    if world == 1 and args.chain_sweep and not args.no_graph and K > 8:
+        for P in [int(x) for x in args.chain_sweep.split(',') if x.strip()]:
+            if P == r.chains or N % P:
+                continue
+            keep = (r.graph, r.head, r.timed_as, r.chains)
+            r.chains = P
+            r._capture()
+            if r.graph is not None and r.graph.chains == P:
+                mP = r.measure(max(3, args.windows // 2), 1)
+                chain_sweep[str(P)] = {'value': N * K / mP['elapsed'], 'ms_per_step': 1e3 * mP['elapsed'] / K,
+                                       'event_span_us_per_step': 1e3 * mP['kernel_ms'], 'windows_ms_per_step': mP['windows_ms_per_step']}
+            else:
+                chain_sweep[str(P)] = {'error': r.timed_as}
+            r.graph, r.head, r.timed_as, r.chains = keep
+    chains_used = r.chains
 
     # secondary: fused T-step rollout (state resident in LDS/registers, in-kernel RNG)
     fused = fused_rec = None
@@ -911,7 +933,8 @@ def run(args):
                    'host': {'usable_cpus': usable_cpus(), 'torch_threads': torch.get_num_threads()},
                    'fused_rollout_env_steps_per_s': fused,
                    'fused_rollout_recorded_actions_env_steps_per_s': fused_rec,
-                   'async_2_subbatches_env_steps_per_s': async2},
+                   'async_2_subbatches_env_steps_per_s': async2,
+                   'chains': chains_used, 'chain_sweep': chain_sweep},
         'roofline': roof,
     }
     if api is not None:

@@ -363,9 +363,14 @@ class VecGridWorld:
         return self._obs.copy(), self.reward, self.done, {}
 
     # ---- a captured step loop (the loop of examples/run_env.py:18-26 as ONE HIP-graph launch) ----
-    def capture_steps(self, actions, record=False):
+    def capture_steps(self, actions, record=False, chains=1):
         """Captures `for t in range(T): env.step(actions[t])` into a HIP graph and returns a StepGraph; replay() launches
-        the T steps in one call (no per-step host work at all), bit-identical to the eager loop.  `actions`: walking int32
+        the T steps in one call (no per-step host work at all), bit-identical to the eager loop.  chains = P > 1 captures
+        the T steps as P INDEPENDENT chains of launches, one per contiguous sub-batch of N / P envs (envs never read one
+        another's state, so the results are the same bytes): the chains are parallel branches of the graph, so the tail
+        of one sub-batch's step t -- the wait for its slowest wavefront -- and the ramp of its step t + 1 overlap the
+        other sub-batches' work instead of idling the chip between two whole-batch launches (Discrete(18) walking and
+        flying / Dict alike; not with the episode log or the RandomTasks generator, which index by context).  `actions`: walking int32
         device tensor [T, N]; flying dict of device tensors movement f32[T,N,3], camera f32[T,N,2], inventory i32[T,N],
         placement i32[T,N]; walking Dict: buttons u8[T,N,8], camera f32[T,N,2].  The graph reads the action BUFFERS at
         replay time: refill them in place (copy_) between replays to step with new actions.  record=True also copies
@@ -376,7 +381,7 @@ class VecGridWorld:
         parameters, frozen at capture; after set_task_sampling / set_random_tasks / enable_ / disable_trajectory_log
         replay() raises (capture again)."""
         self._need_tasks()
-        return StepGraph(self, actions, record)
+        return StepGraph(self, actions, record, chains)
 
     def step_walking_ptr(self, actions_i32):
         """Hot-loop variant: `actions_i32` is already a contiguous int32 device tensor [N]."""
@@ -459,6 +464,13 @@ class VecGridWorld:
         return subs
 
     # ---- introspection ----
+    def stats_tensor(self):
+        """The device counters [8] int64 of this env and its sub-batches as a DEVICE tensor (no synchronisation)."""
+        s = self.stats_buf.sum(0)
+        for c in self._children:
+            s = s + c.stats_buf.sum(0)
+        return s
+
     def stats(self):
         """Device counters of this env and of its sub-batches (VecGridWorld.split).  `steps`: env-steps executed, counted
         on the device by every step launch and fused rollout (`rollout_steps` is the same counter's old name)."""
@@ -499,9 +511,15 @@ class StepGraph:
     """T captured env steps (VecGridWorld.capture_steps).  replay() launches them on the current stream and returns the
     env's (obs, reward, done, info) views, which then hold the LAST step's values."""
 
-    def __init__(self, env, actions, record):
+    def __init__(self, env, actions, record, chains=1):
         self.env = env
         dev, N = env.device, env.num_envs
+        chains = int(chains)
+        if chains < 1 or N % chains:
+            raise ValueError(f'capture_steps: chains must divide num_envs ({N})')
+        if chains > 1 and (env._traj is not None or (env._sampling or ('',))[0] == 'random'):
+            raise L.IgwError('capture_steps(chains > 1) cannot be combined with the episode log or the RandomTasks generator')
+        self.chains = chains
         # A launch is given the kernel parameters BY VALUE: the graph freezes the sampler settings (set_task_sampling,
         # set_random_tasks) and the episode-log buffers (enable / disable_trajectory_log) of the moment of capture.
         # replay() refuses to run after any of them changed (config_epoch), and the graph keeps the log's buffers
@@ -516,13 +534,13 @@ class StepGraph:
         if env.flying:
             self.buffers = (need(actions['movement'], torch.float32, (N, 3), 'movement'), need(actions['camera'], torch.float32, (N, 2), 'camera'),
                             need(actions['inventory'], torch.int32, (N,), 'inventory'), need(actions['placement'], torch.int32, (N,), 'placement'))
-            fn = env.lib.igw_step_flying
+            fn, row_bytes = env.lib.igw_step_flying, (12, 8, 4, 4)
         elif env.walk_dict:
             self.buffers = (need(actions['buttons'], torch.uint8, (N, 8), 'buttons'), need(actions['camera'], torch.float32, (N, 2), 'camera'))
-            fn = env.lib.igw_step_walking_dict
+            fn, row_bytes = env.lib.igw_step_walking_dict, (8, 8)
         else:
             self.buffers = (need(actions, torch.int32, (N,), 'actions'),)
-            fn = env.lib.igw_step_walking
+            fn, row_bytes = env.lib.igw_step_walking, (4,)
         self.T = T = int(self.buffers[0].shape[0])
         if T < 1 or any(b.shape[0] != T for b in self.buffers):
             raise ValueError('capture_steps: every action buffer needs the same number of steps T >= 1')
@@ -532,12 +550,27 @@ class StepGraph:
         cap = torch.cuda.Stream(device=dev)
         cap.wait_stream(torch.cuda.current_stream(dev))
         # (thread-local: other threads of the process -- an RCCL watchdog, a data loader -- may touch the runtime)
+        self.subs = env.split(chains) if chains > 1 else None   # one context per chain (kept alive with the graph)
+        side = [torch.cuda.Stream(device=dev) for _ in range(chains)] if chains > 1 else None
         with torch.cuda.graph(self.graph, stream=cap, capture_error_mode='thread_local'):
-            h = C.c_void_p(cap.cuda_stream)
-            for t in range(T):
-                L.check(fn(env.ctx, *ptrs[t], h), 'step (capture)')
-                if record:
-                    self.outs[t].copy_(env.out_buf)
+            if chains == 1:
+                h = C.c_void_p(cap.cuda_stream)
+                for t in range(T):
+                    L.check(fn(env.ctx, *ptrs[t], h), 'step (capture)')
+                    if record:
+                        self.outs[t].copy_(env.out_buf)
+            else:   # fork: every chain on its own capture stream = a parallel branch of the graph; join at the end
+                for k, sb in enumerate(self.subs):
+                    side[k].wait_stream(cap)
+                    h = C.c_void_p(side[k].cuda_stream)
+                    offs = tuple(b * sb.lo for b in row_bytes)
+                    with torch.cuda.stream(side[k]):
+                        for t in range(T):
+                            L.check(fn(sb.ctx, *(p + o for p, o in zip(ptrs[t], offs)), h), 'step (capture)')
+                            if record:
+                                self.outs[t, sb.lo:sb.lo + sb.num_envs].copy_(env.out_buf[sb.lo:sb.lo + sb.num_envs])
+                for st in side:
+                    cap.wait_stream(st)
         torch.cuda.current_stream(dev).wait_stream(cap)
         if record:
             f = self.outs.view(torch.float32)
@@ -564,6 +597,9 @@ class SubBatch:
         cfg = L.Config.from_buffer_copy(parent.cfg)
         cfg.num_envs = n
         cfg.env_index_base = parent.env_index_base + lo
+        if cfg.lanes_per_env == 0:   # the group width the library chose for the WHOLE batch (include/igw.h: IGW_AUTO_*)
+            N = parent.num_envs
+            cfg.lanes_per_env = 32 if N <= 1024 else 16 if N <= 4096 else 8 if N <= 24576 else 4
         self.cfg = cfg
         self.ctx = C.c_void_p()
         L.check(self.lib.igw_create(C.byref(cfg), C.byref(self.ctx)), 'igw_create')

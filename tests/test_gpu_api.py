@@ -125,3 +125,83 @@ def test_wide_inventory_state_and_rejected_placements(gs):
         for e, c in zip(*np.nonzero(placed)):
             col = int(grid_after[e, c])
             assert before[e, col - 1] > 0 and after[e, col - 1] == before[e, col - 1] - 1
+
+
+@pytest.mark.parametrize('mode,chains', [('walking', 2), ('walking', 4), ('flying', 2), ('walking_dict', 4)])
+def test_step_graph_as_independent_chains_equals_the_eager_loop(mode, chains):
+    """capture_steps(chains=P): the T steps as P parallel chains of sub-batch launches -- same bytes as T eager
+    env.step() calls (state, records, per-step outputs with record=True, device counters), auto-resets and the
+    on-device task sampler included."""
+    from gridworld_amd import IgwError, VecGridWorld, workloads
+    n, T = 4096, 70
+    space = dict(action_space='flying') if mode == 'flying' else dict(discretize=False) if mode == 'walking_dict' else {}
+    kw = dict(size_reward=False, max_steps=25, autoreset=True, num_tasks=37, **space)
+    tg = workloads.rt20(37, seed=5)
+    a, b = VecGridWorld(n, **kw), VecGridWorld(n, **kw)
+    for env in (a, b):
+        env.set_tasks(tg.to(env.device), env_task=np.zeros(n, np.int32))
+        env.set_task_sampling(True, seed=3)
+        env.reset()
+    g = torch.Generator(device=a.device)
+    g.manual_seed(1)
+    dev = a.device
+    if mode == 'walking':
+        acts = torch.randint(0, 18, (T, n), generator=g, device=dev, dtype=torch.int32)
+        step_t = lambda t: acts[t]  # noqa: E731
+    elif mode == 'flying':
+        acts = dict(movement=torch.rand((T, n, 3), generator=g, device=dev) * 2 - 1, camera=torch.rand((T, n, 2), generator=g, device=dev) * 10 - 5,
+                    inventory=torch.randint(0, 7, (T, n), generator=g, device=dev, dtype=torch.int32),
+                    placement=torch.randint(0, 3, (T, n), generator=g, device=dev, dtype=torch.int32))
+        step_t = lambda t: {k: v[t] for k, v in acts.items()}  # noqa: E731
+    else:
+        acts = dict(buttons=(torch.rand((T, n, 8), generator=g, device=dev) < 0.3).to(torch.uint8),
+                    camera=torch.rand((T, n, 2), generator=g, device=dev) * 10 - 5)
+        acts['buttons'][:, :, 7] = torch.randint(0, 7, (T, n), generator=g, device=dev).to(torch.uint8)
+        step_t = lambda t: {k: v[t] for k, v in acts.items()}  # noqa: E731
+    graph = a.capture_steps(acts, record=True, chains=chains)
+    assert graph.chains == chains and len(graph.subs) == chains
+    graph.replay()
+    outs = []
+    for t in range(T):
+        b.step(step_t(t))
+        outs.append(b.out_buf.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(graph.outs, torch.stack(outs))
+    for name in ('grid_buf', 'occ_buf', 'hist_buf', 'agent_buf', 'aux_buf', 'out_buf'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    sa, sb = a.stats(), b.stats()
+    assert sa == sb and sa['steps'] == n * T and sa['resets'] > 0
+    a.set_task_sampling(True, seed=4)         # the settings are kernel parameters of the captured launches
+    with pytest.raises(IgwError):
+        graph.replay()
+    with pytest.raises(ValueError):
+        a.capture_steps(acts, chains=3)
+
+
+def test_step_graph_refuses_to_replay_a_stale_configuration():
+    """A captured launch carries the kernel parameters by value: after the episode log is switched on or off (or a
+    sampler is reconfigured) replay() raises instead of running the old settings -- or writing into the log buffers
+    that were freed (the graph also keeps the buffers of its capture alive)."""
+    from gridworld_amd import IgwError, VecGridWorld, workloads
+    n, T = 256, 8
+    env = VecGridWorld(n, size_reward=False, autoreset=True, max_steps=5)
+    env.set_tasks(workloads.rt20(n, seed=1).to(env.device))
+    env.reset()
+    acts = env.fill_actions(T, seed=2)
+    rec, heads = env.enable_trajectory_log(4)
+    g1 = env.capture_steps(acts)
+    g1.replay()
+    torch.cuda.synchronize()
+    assert int(heads[:, :, 1].max()) > 0 and g1._held[0] is rec
+    env.disable_trajectory_log()
+    del rec, heads
+    with pytest.raises(IgwError):
+        g1.replay()
+    g2 = env.capture_steps(acts)
+    g2.replay()
+    env.set_random_tasks(True, seed=1)
+    with pytest.raises(IgwError):
+        g2.replay()
+    d = env.dense()
+    assert all(v.is_contiguous() for v in d.values()) and d['done'].shape == (n,) and d['reward'].stride() == (1,)
+    assert env.reward.stride() == (16,) and env.done.stride() == (64,)   # the documented strides of the views

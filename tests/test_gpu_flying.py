@@ -267,3 +267,15 @@ def test_device_trig_self_check():
     assert not (fl & 8).any(), 'device atan2: the quick evaluation accepted a wrong rounding'
     assert (fl[:typical] & 1).astype(bool).mean() > 0.9999
     assert (fl[:typical] & 4).astype(bool).mean() > 0.9999
+    # acceptance rates of the quick evaluations on the configs[3] argument distribution (angles of a flying agent in
+    # radians; float32 strafe pairs in [-1, 1]^2): how often the accurate double-double path runs at all
+    import json
+    import os
+    i0 = len(a) - n - 6   # the block of float32 (y, x) pairs
+    sc, at2 = (fl[:n] & 1).astype(bool), (fl[i0:i0 + n] & 4).astype(bool)
+    rates = dict(sincos_quick_accepted=float(sc.mean()), sincos_rejected=int((~sc).sum()), sincos_arguments=int(n),
+                 atan2_quick_accepted=float(at2.mean()), atan2_rejected=int((~at2).sum()), atan2_arguments=int(n))
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/trig_quick_acceptance.json', 'w') as f:
+        json.dump(rates, f, indent=1)
+    print('\nquick-path acceptance:', json.dumps(rates))
