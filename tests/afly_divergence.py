@@ -47,14 +47,16 @@ def one_pass(N, T, seed, ob=None, grid_every=10, cores=None):
     first_int = np.full(N, -1)           # first step at which grid / inventory / reward / done differ
     first_f32 = np.full(N, -1)           # first step at which agentPos / compass (float32) differ
     dev = env.device
+    cases, hist = [], []       # details of the first few integer divergences; the last steps' actions (host copies)
     for t in range(T):
         a = dict(movement=torch.rand((N, 3), generator=g, device=dev) * 2 - 1,
                  camera=torch.rand((N, 2), generator=g, device=dev) * 10 - 5,
                  inventory=torch.randint(0, 7, (N,), generator=g, device=dev, dtype=torch.int32),
                  placement=torch.randint(0, 3, (N,), generator=g, device=dev, dtype=torch.int32))
         env.step(a)
-        ob.step_flying(a['movement'].cpu().numpy(), a['camera'].cpu().numpy(), a['inventory'].cpu().numpy(),
-                       a['placement'].cpu().numpy(), nthreads=cores)
+        ah = (a['movement'].cpu().numpy(), a['camera'].cpu().numpy(), a['inventory'].cpu().numpy(), a['placement'].cpu().numpy())
+        hist = (hist + [ah])[-8:]
+        ob.step_flying(*ah, nthreads=cores)
         out = env.out_buf.cpu().numpy()                  # one copy: the 64-byte output records (include/igw.h)
         f = out[:, :52].copy().view(np.float32)
         d_int = (out[:, 52] != ob.done) | (f[:, 12] != ob.reward) | (f[:, 5:11] != ob.inventory).any(-1)
@@ -62,6 +64,20 @@ def one_pass(N, T, seed, ob=None, grid_every=10, cores=None):
             d_int |= (env.grid_buf.cpu().numpy()[:, :1089] != ob.grid).any(-1)
         d_f32 = (f[:, :5].view(np.uint32) != ob.agentPos.view(np.uint32)).any(-1) | \
             (f[:, 11].view(np.uint32) != ob.compass.view(np.uint32))
+        new_int = np.nonzero((first_int < 0) & d_int)[0]
+        if len(new_int) and len(cases) < 16:     # rare: what the two sides hold right after the diverging step
+            di = env.internals()
+            for e in new_int[:4]:
+                k0 = t + 1 - len(hist)
+                cases.append(dict(env=int(e), step=t, device=dict(done=int(out[e, 52]), reward=float(f[e, 12]), inventory=f[e, 5:11].tolist(),
+                                                                  agentPos=f[e, :5].tolist(), internal=[float(v).hex() for v in di[e]]),
+                                  oracle_glibc=dict(done=int(ob.done[e]), reward=float(ob.reward[e]), inventory=ob.inventory[e].tolist(),
+                                                    agentPos=ob.agentPos[e].tolist(), internal=[float(v).hex() for v in ob.envs[e].internal()]),
+                                  grid_cells_that_differ=np.nonzero(env.grid_buf[e].cpu().numpy()[:1089] != ob.grid[e])[0].tolist(),
+                                  target_cells=np.nonzero(tg[e].numpy().reshape(-1))[0].tolist(),
+                                  actions_from_step=k0,
+                                  actions=[dict(movement=[float(v) for v in h[0][e]], camera=[float(v) for v in h[1][e]],
+                                                inventory=int(h[2][e]), placement=int(h[3][e])) for h in hist]))
         first_int[(first_int < 0) & d_int] = t
         first_f32[(first_f32 < 0) & d_f32] = t
     fin = env.internals()
@@ -78,7 +94,7 @@ def one_pass(N, T, seed, ob=None, grid_every=10, cores=None):
                exposure_float32=int(np.where(first_f32 >= 0, first_f32 + 1, T).sum()),
                envs_ending_with_a_float64_difference=int(diff64.sum()),
                max_abs_float64_deviation_of_clean_envs=float(np.abs(fin[clean, :6] - ref[clean, :6]).max()) if clean.any() else None,
-               all_done=bool(env.done.all()), min_inventory=int(env.inventory.min()))
+               all_done=bool(env.done.all()), min_inventory=int(env.inventory.min()), integer_divergence_cases=cases)
     return res, ob
 
 
@@ -94,6 +110,7 @@ def summarize(passes, wall):
         what='HIP flying path (own correctly rounded trig) vs the CPU oracle with GLIBC trig, every env, every step',
         env_steps_compared=sum(p['env_steps'] for p in passes), passes=len(passes),
         integer_divergences=n_int, float32_obs_divergences=n_f32,
+        integer_divergence_cases=[c for p in passes for c in p.get('integer_divergence_cases', [])],
         envs_ending_with_a_float64_difference=sum(p['envs_ending_with_a_float64_difference'] for p in passes),
         float64_difference_rate_per_episode=sum(p['envs_ending_with_a_float64_difference'] for p in passes) /
         float(sum(p['envs'] for p in passes)),
@@ -113,12 +130,14 @@ def main():
     ap.add_argument('--envs', type=int, default=65536)
     ap.add_argument('--steps', type=int, default=250)
     ap.add_argument('--seed0', type=int, default=9000)
+    ap.add_argument('--seeds', default='', help='explicit comma-separated seeds instead of seed0 .. seed0 + passes - 1')
     ap.add_argument('--out', default='gpurun_out/afly_divergence.json')
     a = ap.parse_args()
     t0 = time.time()
     passes, ob = [], None
-    for k in range(a.passes):
-        r, ob = one_pass(a.envs, a.steps, a.seed0 + k, ob)
+    seeds = [int(x) for x in a.seeds.split(',') if x] or [a.seed0 + k for k in range(a.passes)]
+    for sd in seeds:
+        r, ob = one_pass(a.envs, a.steps, sd, ob)
         passes.append(r)
         print(json.dumps(r), flush=True)
     s = summarize(passes, time.time() - t0)
