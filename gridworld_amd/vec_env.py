@@ -367,10 +367,10 @@ class VecGridWorld:
         """Captures `for t in range(T): env.step(actions[t])` into a HIP graph and returns a StepGraph; replay() launches
         the T steps in one call (no per-step host work at all), bit-identical to the eager loop.  chains = P > 1 captures
         the T steps as P INDEPENDENT chains of launches, one per contiguous sub-batch of N / P envs (envs never read one
-        another's state, so the results are the same bytes): the chains are parallel branches of the graph, so the tail
-        of one sub-batch's step t -- the wait for its slowest wavefront -- and the ramp of its step t + 1 overlap the
-        other sub-batches' work instead of idling the chip between two whole-batch launches (Discrete(18) walking and
-        flying / Dict alike; not with the episode log or the RandomTasks generator, which index by context).  `actions`: walking int32
+        another's state, so the results are the same bytes), each a linear graph replayed on its own stream: the tail
+        of one sub-batch's step t -- the wait for its slowest wavefront -- and the ramp of its step t + 1 can overlap the
+        other sub-batches' work instead of idling the chip between two whole-batch launches (all action spaces; not
+        with the episode log or the RandomTasks generator, which index by context).  `actions`: walking int32
         device tensor [T, N]; flying dict of device tensors movement f32[T,N,3], camera f32[T,N,2], inventory i32[T,N],
         placement i32[T,N]; walking Dict: buttons u8[T,N,8], camera f32[T,N,2].  The graph reads the action BUFFERS at
         replay time: refill them in place (copy_) between replays to step with new actions.  record=True also copies
@@ -550,28 +550,26 @@ class StepGraph:
         cap = torch.cuda.Stream(device=dev)
         cap.wait_stream(torch.cuda.current_stream(dev))
         # (thread-local: other threads of the process -- an RCCL watchdog, a data loader -- may touch the runtime)
-        self.subs = env.split(chains) if chains > 1 else None   # one context per chain (kept alive with the graph)
-        side = [torch.cuda.Stream(device=dev) for _ in range(chains)] if chains > 1 else None
-        with torch.cuda.graph(self.graph, stream=cap, capture_error_mode='thread_local'):
-            if chains == 1:
-                h = C.c_void_p(cap.cuda_stream)
+        # chains > 1: one context, one stream and ONE LINEAR GRAPH per chain, replayed side by side on their streams.
+        # (Measured, profiles/r05_chains.txt: captured as parallel BRANCHES of one graph the chains do not overlap --
+        # the runtime executes the branches one after the other, 2 / 4 / 8 branches cost 12.3 / 16.6 / 25.6 us per
+        # step against 10.9 for the single chain -- while kernels of different STREAMS do run concurrently.)
+        self.subs = env.split(chains) if chains > 1 else None   # (kept alive with the graphs)
+        self.graphs = [self.graph] + [torch.cuda.CUDAGraph() for _ in range(chains - 1)]
+        self.streams = [cap] + [torch.cuda.Stream(device=dev) for _ in range(chains - 1)]
+        for k in range(chains):
+            st = self.streams[k]
+            st.wait_stream(torch.cuda.current_stream(dev))
+            ctx = env.ctx if chains == 1 else self.subs[k].ctx
+            lo, n = (0, N) if chains == 1 else (self.subs[k].lo, self.subs[k].num_envs)
+            offs = tuple(b * lo for b in row_bytes)
+            with torch.cuda.graph(self.graphs[k], stream=st, capture_error_mode='thread_local'):
+                h = C.c_void_p(st.cuda_stream)
                 for t in range(T):
-                    L.check(fn(env.ctx, *ptrs[t], h), 'step (capture)')
+                    L.check(fn(ctx, *(p + o for p, o in zip(ptrs[t], offs)), h), 'step (capture)')
                     if record:
-                        self.outs[t].copy_(env.out_buf)
-            else:   # fork: every chain on its own capture stream = a parallel branch of the graph; join at the end
-                for k, sb in enumerate(self.subs):
-                    side[k].wait_stream(cap)
-                    h = C.c_void_p(side[k].cuda_stream)
-                    offs = tuple(b * sb.lo for b in row_bytes)
-                    with torch.cuda.stream(side[k]):
-                        for t in range(T):
-                            L.check(fn(sb.ctx, *(p + o for p, o in zip(ptrs[t], offs)), h), 'step (capture)')
-                            if record:
-                                self.outs[t, sb.lo:sb.lo + sb.num_envs].copy_(env.out_buf[sb.lo:sb.lo + sb.num_envs])
-                for st in side:
-                    cap.wait_stream(st)
-        torch.cuda.current_stream(dev).wait_stream(cap)
+                        self.outs[t, lo:lo + n].copy_(env.out_buf[lo:lo + n])
+            torch.cuda.current_stream(dev).wait_stream(st)
         if record:
             f = self.outs.view(torch.float32)
             self.rewards, self.dones = f[:, :, 12], self.outs[:, :, 52]
@@ -582,7 +580,16 @@ class StepGraph:
             raise L.IgwError('StepGraph is stale: set_task_sampling / set_random_tasks / enable_trajectory_log / '
                              'disable_trajectory_log was called after capture_steps (a captured launch carries those '
                              'settings by value); capture the steps again')
-        self.graph.replay()
+        if self.chains == 1:
+            self.graph.replay()
+        else:   # fork: every chain's stream waits for the caller's stream, runs its graph; the caller's stream joins
+            cur = torch.cuda.current_stream(env.device)
+            for g, st in zip(self.graphs, self.streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    g.replay()
+            for st in self.streams:
+                cur.wait_stream(st)
         return env._obs.copy(), env.reward, env.done, {}
 
 

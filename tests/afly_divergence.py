@@ -27,7 +27,11 @@ import numpy as np  # noqa: E402
 
 def one_pass(N, T, seed, ob=None, grid_every=10, cores=None):
     """One batch of N flying envs for T steps (max_steps = T: every episode runs its full length, no resets).
-    Returns (result dict, the OracleBatch for reuse)."""
+    Returns (result dict, the OracleBatch).  Both sides start from FRESH agents: an Agent's active_block, dy and
+    time_int_steps survive reset() in the reference, so an OracleBatch that has been stepped before is not
+    in the state a new VecGridWorld is in (the first 7-pass run of this script reused one: 3 'divergences' at steps
+    2-3, all of them placements with the colour left over from the previous pass -- profiles/r05_afly_divergence.json
+    keeps that run's cases as a record of what the comparison catches)."""
     import torch
     from gridworld_amd import VecGridWorld, workloads
     from oracle import oracle as O
@@ -37,8 +41,7 @@ def one_pass(N, T, seed, ob=None, grid_every=10, cores=None):
     env = VecGridWorld(N, autoreset=False, **kw)
     env.set_tasks(tg.to(env.device))
     env.reset()
-    if ob is None:
-        ob = O.OracleBatch(N, **kw)          # default trig mode: libm (glibc)
+    ob = O.OracleBatch(N, **kw)              # fresh agents; default trig mode: libm (glibc)
     O.use_device_trig(False)
     ob.set_tasks(tg.numpy())
     ob.reset()

@@ -170,10 +170,11 @@ def test_flying_divergence_from_glibc_reference_at_scale(capsys):
     assert res['env_steps'] == 65536 * 250
     # every env of the full batch finished its episode and the invariants of the domain hold
     assert res['all_done'] and res['min_inventory'] >= 0
-    # integer outputs: a handful of episodes per 16 M env-steps at most; float32 observations: last-bit flips in < 1 %
-    # of the episodes; the float64 trajectories themselves part in the last bits of a few per cent of the episodes
-    assert res['envs_with_integer_divergence'] <= N // 2000
-    assert res['envs_with_float32_obs_divergence'] <= N // 100
+    # the float64 trajectories part in the last bits of ~2.4 % of the episodes (glibc's 1-ulp misroundings); that
+    # reaches an output only by flipping a rounding
+    # (the 1.15e8-step run saw none of either kind: rates below 2.6e-8 per env-step, i.e. < 0.5 expected here)
+    assert res['envs_with_integer_divergence'] <= 2
+    assert res['envs_with_float32_obs_divergence'] <= 8
     assert res['max_abs_float64_deviation_of_clean_envs'] < 1e-9
 
 
