@@ -76,12 +76,16 @@ def parse_args(argv=None):
                     help='passes through the whole W + K sequence before the measured windows (reported, not counted)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
-    ap.add_argument('--no-async', action='store_true', help='skip the secondary two-sub-batch measurement')
+    ap.add_argument('--no-async', action='store_true', help='(kept for old command lines; the two-sub-batch figure needs --async now)')
+    ap.add_argument('--async', dest='do_async', action='store_true',
+                    help='also time two sub-batches launched eagerly on two streams (host-bound at long windows; profiles/r05_chains.txt)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the flying / cdm secondary windows of the default run')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of one HIP-graph replay')
     ap.add_argument('--chains', type=int, default=1,
                     help='capture the timed steps as this many independent chains of sub-batch launches (VecGridWorld.capture_steps(chains=))')
-    ap.add_argument('--chain-sweep', default='2,4', help='also measure these chain counts (config.chain_sweep); empty = none')
+    ap.add_argument('--chain-sweep', default='',
+                    help='also measure these chain counts, e.g. 2,4 (config.chain_sweep); measured slower than one chain on MI355X '
+                         '(profiles/r05_chains.txt), so not part of the default run')
     ap.add_argument('--no-api', action='store_true', help='skip the public-API loop measurements (config.api_*)')
     ap.add_argument('--lockstep', action='store_true',
                     help='skip the episode de-synchronisation (round-1 behaviour: all envs at the same episode step)')
@@ -805,7 +809,7 @@ def run(args):
     # EnvPool-style asynchronous mode): no barrier between the halves, so the start of one half's next step
     # fills the end of the other's -- what one launch per step over the whole batch cannot do
     async2 = None
-    if not args.no_async and not flying and N % 2 == 0:
+    if args.do_async and not flying and N % 2 == 0:
         subs = env.split(2)
         jobs = [(sb.ctx, ctypes.c_void_p(sb.stream.cuda_stream), 4 * sb.lo) for sb in subs]
         Ka = min(K, W + K)
@@ -933,8 +937,9 @@ def run(args):
                    'host': {'usable_cpus': usable_cpus(), 'torch_threads': torch.get_num_threads()},
                    'fused_rollout_env_steps_per_s': fused,
                    'fused_rollout_recorded_actions_env_steps_per_s': fused_rec,
-                   'async_2_subbatches_env_steps_per_s': async2,
-                   'chains': chains_used, 'chain_sweep': chain_sweep},
+                   'chains': chains_used,
+                   'overlap_note': 'concurrent sub-batch launches (two streams, parallel graph branches, one graph per stream) are '
+                                   'all slower than one whole-batch launch per step on this part: profiles/r05_chains.txt'},
         'roofline': roof,
     }
     if api is not None:
@@ -949,6 +954,10 @@ def run(args):
                                          'graph': {k: (v / head if v else None) for k, v in api['graph'].items()}}
         if 'graph_error' in api:
             out['config']['api_graph_error'] = api['graph_error']
+    if async2 is not None:
+        out['config']['async_2_subbatches_env_steps_per_s'] = async2
+    if chain_sweep:
+        out['config']['chain_sweep'] = chain_sweep
     out['config'].update(secondary)
     if small is not None:
         out['config']['small'] = small
