@@ -664,7 +664,7 @@ def facade_rate(seed, steps=3000):
     """The latency end of the API -- BASELINE configs[0] through the reference's own calling sequence on the HIP path:
     gridworld_amd.make('IGLUGridworldVector-v0') (create_env defaults: Discrete(18), SizeReward, select_and_place), the
     DUMMY_TASK-equivalent task, `obs, reward, done, info = env.step(int)` with numpy observations, reset on done.
-    Every step is one HIP-graph replay (action upload, step kernel, 1.2 KB read-back) + one stream synchronisation.
+    Every step is one kernel launch + one stream synchronisation (records, grid and action in pinned host memory).
     Timed as examples/run_env.py:18-26 does (step() only) and including the resets."""
     import numpy as np
     import gridworld_amd as G
@@ -690,9 +690,9 @@ def facade_rate(seed, steps=3000):
     return {'workload': 'configs[0]: 1 env, walking Discrete(18), DUMMY_TASK-equivalent task, gym.make defaults, numpy '
                         'observations, reset on done',
             'steps': steps, 'resets': n_reset, 'steps_per_s_step_only': steps / t_step, 'steps_per_s_incl_resets': steps / wall,
-            'us_per_step': 1e6 * t_step / steps, 'graph': env.unwrapped._graph is not None,
-            'how': 'one HIP-graph replay (action upload, step_kernel<32,...>, 1.2 KB read-back into pinned memory) + one '
-                   'stream synchronisation per step',
+            'us_per_step': 1e6 * t_step / steps,
+            'how': 'one launch of step_kernel<32,...> + one stream synchronisation per step; the env\'s records, grid and '
+                   'action live in pinned host memory the kernel reads and writes across PCIe (no copies)',
             'reference_python_here': 'BASELINE.md: 3.8-4.2 k steps/s step only, 2.9-3.2 k incl. resets (build container, 1 core)'}
 
 

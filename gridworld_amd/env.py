@@ -6,9 +6,9 @@ observation dict, dtypes and errors.
     env.set_task(task); obs = env.reset(); obs, reward, done, info = env.step(action)
     env.unwrapped            # the GridWorld; .agent / .world / .grid / .step_no / .max_int as in the reference
 
-It drives a VecGridWorld with N = 1.  A step is ONE replay of a captured HIP graph -- action host -> device, the step
-kernel, one device -> host copy of the env's records and grid (VecGridWorld.host_view, 1.2 KB, into pinned memory)
--- and one stream synchronisation; the observation arrays are fresh numpy copies, as the reference's are."""
+It drives a VecGridWorld with N = 1 whose records, grid and action live in pinned host memory the kernel reads and
+writes itself: a step is one kernel launch and one stream synchronisation, no copies; the observation arrays are
+fresh numpy copies of that memory, as the reference's are fresh arrays."""
 import ctypes as C
 import warnings
 
@@ -19,18 +19,6 @@ from . import _lib as L
 from . import spaces
 from .tasks import Task, Tasks
 from .vec_env import VecGridWorld
-
-_HIP_H2D, _HIP_D2H = 1, 2   # hipMemcpyKind
-
-
-def _hip_runtime():
-    """The HIP runtime torch already loaded, for hipMemcpyAsync (plumbing: two tiny copies per step that must be
-    capturable into a graph without the caching host allocator's bookkeeping)."""
-    rt = C.CDLL('libamdhip64.so')
-    rt.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    rt.hipMemcpyAsync.restype = C.c_int
-    return rt
-
 
 _NO_TASK = ('Task is not initialized! Initialize task before working with the environment using .set_task '
             'method OR set tasks distribution using .set_task_generator method')
@@ -133,7 +121,8 @@ class GridWorld:
         # the device never computes SizeReward here: it is the reference's Python wrapper around this env (below)
         self._vec = VecGridWorld(1, device=device, action_space=action_space, select_and_place=select_and_place,
                                  size_reward=False, max_steps=max_steps, right_placement_scale=right_placement_scale,
-                                 discretize=discretize, wrong_placement_scale=wrong_placement_scale, num_tasks=1)
+                                 discretize=discretize, wrong_placement_scale=wrong_placement_scale, num_tasks=1,
+                                 host_records=True)
         self._task = None
         self._task_generator = None
         self._overwrite_starting_grid = None
@@ -175,84 +164,44 @@ class GridWorld:
 
     # -- the host <-> device path of one step ---------------------------------------------------------------------
     def _init_host_path(self):
-        """Pinned host mirrors of the env's records + grid (one device -> host copy per step) and of the action (one
-        host -> device copy), and the numpy views the Python side reads / writes."""
+        """The env's records and grid live in pinned, device-mapped HOST memory (VecGridWorld(host_records=True)) and
+        so does the action: the step kernel reads its 84 bytes of per-env input and writes its 144 bytes of records
+        across PCIe itself, and a step costs the host one launch and one stream synchronisation -- no copy in either
+        direction (a copy engine round trip costs more than the kernel).  The numpy views below alias that memory."""
         v = self._vec
-        dev = v.device
-        self._pin = torch.zeros(v.host_view.numel(), dtype=torch.uint8).pin_memory()
-        h = self._pin.numpy()
+        h = v.host_view.numpy()
         o, a, x = L.OUT_BYTES, L.AGENT_BYTES, L.AUX_BYTES
         self._host = {'out': h[:o], 'agent': h[o:o + a], 'aux': h[o + a:o + a + x],
                       'grid': h[o + a + x:o + a + x + L.CELLS].view(np.int8)}
         self._out_f32 = self._host['out'][:52].view(np.float32)
         self._aux_i16 = self._host['aux'][:8].view(np.int16)
-        # action staging, 40 bytes: walking action i32 / Dict buttons u8[8] at 0, camera f32[2] at 8, movement f32[3]
-        # at 16, inventory i32 at 28, placement i32 at 32
+        # the action, 40 bytes of pinned host memory: walking action i32 / Dict buttons u8[8] at 0, camera f32[2] at 8,
+        # movement f32[3] at 16, inventory i32 at 28, placement i32 at 32
         self._act_pin = torch.zeros(40, dtype=torch.uint8).pin_memory()
-        self._act_dev = torch.zeros(40, dtype=torch.uint8, device=dev)
         ah = self._act_pin.numpy()
         self._act = {'walk': ah[0:4].view(np.int32), 'buttons': ah[0:8], 'camera': ah[8:16].view(np.float32),
                      'movement': ah[16:28].view(np.float32), 'inventory': ah[28:32].view(np.int32),
                      'placement': ah[32:36].view(np.int32)}
-        self._graph = None
-        self._graph_epoch = -1
-        self._stream = torch.cuda.Stream(device=dev)   # the env's own stream: step() never waits for other work
-        self._hip = _hip_runtime()
+        self._stream = torch.cuda.Stream(device=v.device)   # the env's own stream: step() never waits for other work
+        self._stream_handle = C.c_void_p(self._stream.cuda_stream)
+        p = self._act_pin.data_ptr()
+        if v.flying:
+            self._step_call = lambda: v.lib.igw_step_flying(v.ctx, p + 16, p + 8, p + 28, p + 32, self._stream_handle)
+        elif v.walk_dict:
+            self._step_call = lambda: v.lib.igw_step_walking_dict(v.ctx, p, p + 8, self._stream_handle)
+        else:
+            self._step_call = lambda: v.lib.igw_step_walking(v.ctx, p, self._stream_handle)
         self._read_back()   # a fresh Agent (core/world.py:12-29): inventory 20 x 6, BLUE active, time_int_steps 2
 
-    def _issue_step(self):
-        """action host -> device, the step kernel, records + grid device -> host; all on the env's stream."""
-        v, h = self._vec, C.c_void_p(self._stream.cuda_stream)
-        cp = self._hip.hipMemcpyAsync
-        if cp(self._act_dev.data_ptr(), self._act_pin.data_ptr(), self._act_pin.numel(), _HIP_H2D, h):
-            raise L.IgwError('hipMemcpyAsync (action) failed')
-        self._launch_step(h)
-        if cp(self._pin.data_ptr(), v.host_view.data_ptr(), self._pin.numel(), _HIP_D2H, h):
-            raise L.IgwError('hipMemcpyAsync (read-back) failed')
-
-    def _launch_step(self, stream_handle):
-        v, p = self._vec, self._act_dev.data_ptr()
-        if v.flying:
-            rc = v.lib.igw_step_flying(v.ctx, p + 16, p + 8, p + 28, p + 32, stream_handle)
-        elif v.walk_dict:
-            rc = v.lib.igw_step_walking_dict(v.ctx, p, p + 8, stream_handle)
-        else:
-            rc = v.lib.igw_step_walking(v.ctx, p, stream_handle)
-        L.check(rc, 'igw_step (facade)')
-
-    def _capture(self):
-        """action copy + step kernel + read-back as one HIP graph (re-captured when the episode log is switched:
-        a captured launch carries the kernel parameters by value, VecGridWorld.config_epoch)."""
-        v = self._vec
-        g = torch.cuda.CUDAGraph()
-        self._stream.synchronize()
-        try:
-            with torch.cuda.graph(g, stream=self._stream, capture_error_mode='thread_local'):
-                self._issue_step()
-            self._graph = g
-        except Exception:   # noqa: BLE001 -- no graph: the same three operations are issued one by one
-            self._graph = None
-            torch.cuda.synchronize(v.device)
-        self._graph_epoch = v.config_epoch
-
     def _device_step(self):
-        v = self._vec
-        if self._graph_epoch != v.config_epoch:
-            self._capture()
-        if self._graph is not None:
-            with torch.cuda.stream(self._stream):
-                self._graph.replay()
-        else:
-            self._issue_step()
+        rc = self._step_call()
+        if rc:
+            L.check(rc, 'igw_step (facade)')
         self._stream.synchronize()
 
     def _read_back(self):
-        """After work issued through the VecGridWorld on the current stream (task upload, reset)."""
-        self._stream.wait_stream(torch.cuda.current_stream(self._vec.device))
-        if self._hip.hipMemcpyAsync(self._pin.data_ptr(), self._vec.host_view.data_ptr(), self._pin.numel(), _HIP_D2H,
-                                    C.c_void_p(self._stream.cuda_stream)):
-            raise L.IgwError('hipMemcpyAsync (read-back) failed')
-        self._stream.synchronize()
+        """After work issued through the VecGridWorld on the current stream (task upload, reset): wait for it."""
+        torch.cuda.current_stream(self._vec.device).synchronize()
 
     @property
     def unwrapped(self):

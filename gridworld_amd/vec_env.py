@@ -36,11 +36,13 @@ class VecGridWorld:
     def __init__(self, num_envs, device='cuda:0', action_space='walking', select_and_place=True,
                  size_reward=True, max_steps=250, right_placement_scale=1., wrong_placement_scale=0.1,
                  discretize=True, autoreset=False, num_tasks=None, lanes_per_env=0, debug_flags=0, env_index_base=0,
-                 render=False, render_size=(64, 64), target_in_obs=False, vector_state=True, name='', fake=False):
+                 host_records=False, render=False, render_size=(64, 64), target_in_obs=False, vector_state=True, name='', fake=False):
         """create_env's keyword arguments (gridworld/env.py:333-338) plus the batch's own: num_envs, device,
         autoreset (reset inside step), num_tasks (rows of the task table, default num_envs), lanes_per_env
         (0 = automatic), env_index_base (global index of env 0: rank / sub-batch offset), debug_flags (IGW_DIAG
-        build only).  Anything else is a TypeError, as in create_env.  render / render_size / fake / name /
+        build only), host_records (the output / agent / aux records and the grid live in PINNED HOST memory that the
+        kernels read and write across PCIe: a host-side consumer of a FEW envs -- the 1-env gym facade -- then needs no
+        copy at all, only a stream synchronisation; the observation tensors are CPU tensors in that case).  Anything else is a TypeError, as in create_env.  render / render_size / fake / name /
         target_in_obs / vector_state are accepted for signature compatibility: this is the render=False,
         vector_state=True path (observations are the state tensors; `targets()` gives the target grids)."""
         if render and not fake:
@@ -62,7 +64,11 @@ class VecGridWorld:
         # What a host-side consumer reads back after a step -- output, agent and aux records, the grid -- comes from ONE
         # allocation (`host_view`), so the 1-env facade moves it with a single device-to-host copy (gridworld_amd/env.py)
         rec = L.OUT_BYTES + L.AGENT_BYTES + L.AUX_BYTES
-        self.host_view = z((N * (rec + L.GRID_STRIDE),), torch.uint8)
+        self.host_records = bool(host_records)
+        if self.host_records:   # pinned, device-mapped host memory (hipHostMalloc): the same address on both sides
+            self.host_view = torch.zeros((N * (rec + L.GRID_STRIDE),), dtype=torch.uint8).pin_memory()
+        else:
+            self.host_view = z((N * (rec + L.GRID_STRIDE),), torch.uint8)
         cut = lambda lo, width: self.host_view[N * lo:N * (lo + width)].view(N, width)  # noqa: E731
         self.out_buf = cut(0, L.OUT_BYTES)         # agentPos, inventory, compass, reward, done of every step
         self.agent_buf = cut(L.OUT_BYTES, L.AGENT_BYTES)   # pose, inventory, step_no, pack (include/igw.h)
@@ -503,7 +509,7 @@ class VecGridWorld:
 
     def set_step_no(self, step_no):
         """Overwrites GridWorld.step_no of every env (int tensor / array [N]): de-synchronises the episodes of a batch."""
-        sn = torch.as_tensor(step_no, device=self.device).to(torch.int16).reshape(self.num_envs)
+        sn = torch.as_tensor(step_no).to(device=self.agent_buf.device, dtype=torch.int16).reshape(self.num_envs)
         self.agent_buf.view(torch.int16)[:, 30] = sn
 
 
