@@ -205,3 +205,29 @@ def test_step_graph_refuses_to_replay_a_stale_configuration():
     d = env.dense()
     assert all(v.is_contiguous() for v in d.values()) and d['done'].shape == (n,) and d['reward'].stride() == (1,)
     assert env.reward.stride() == (16,) and env.done.stride() == (64,)   # the documented strides of the views
+
+
+def test_host_resident_records_equal_device_resident():
+    """VecGridWorld(host_records=True): output / agent / aux records and the grid in pinned host memory that the kernels
+    read and write across PCIe (what the 1-env facade runs on) -- the same bytes as the device-resident batch, step by
+    step, auto-resets included; the observation tensors are CPU tensors that alias that memory."""
+    from gridworld_amd import VecGridWorld, workloads
+    n, T = 200, 90
+    kw = dict(size_reward=True, max_steps=30, autoreset=True)
+    tg = workloads.rt20(n, seed=9)
+    a, b = VecGridWorld(n, host_records=True, **kw), VecGridWorld(n, **kw)
+    assert not a.out_buf.is_cuda and a.host_view.is_pinned() and b.out_buf.is_cuda
+    for env in (a, b):
+        env.set_tasks(tg.to(env.device))
+        env.reset()
+    acts = b.fill_actions(T, seed=4)
+    for t in range(T):
+        oa, ra, da, _ = a.step(acts[t])
+        ob, rb, db, _ = b.step(acts[t])
+        torch.cuda.synchronize()
+        assert torch.equal(a.out_buf, b.out_buf.cpu()) and torch.equal(a.agent_buf, b.agent_buf.cpu()), t
+        assert torch.equal(oa['grid'], ob['grid'].cpu()) and torch.equal(ra, rb.cpu()) and torch.equal(da, db.cpu())
+    assert torch.equal(a.aux_buf, b.aux_buf.cpu()) and torch.equal(a.hist_buf, b.hist_buf) and torch.equal(a.occ_buf, b.occ_buf)
+    sa, sb = a.stats(), b.stats()
+    assert sa == sb and sa['steps'] == n * T and sa['resets'] > 0
+    assert np.array_equal(a.internals().view(np.uint64), b.internals().view(np.uint64))
