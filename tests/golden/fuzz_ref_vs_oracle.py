@@ -27,373 +27,79 @@ and the reset observation / internals at every reset.  A scenario draws
 
     python tests/golden/fuzz_ref_vs_oracle.py --scenarios 20000 --procs 8 --out profiles/r05_fuzz_ref_vs_oracle.json
 
-tests/test_ref_fuzz.py runs a 200-scenario slice of this when /root/reference exists.
+tests/test_ref_fuzz.py runs a 200-scenario slice of this when /root/reference exists.  The scenario generator itself
+is tests/scenario_fuzz.py, shared with the product-side run of the SAME seeds on the GPU (tests/test_gpu_facade_fuzz.py:
+gridworld_amd.make(...) against the oracle).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
 import time
-import warnings
-
-import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-for p in (HERE, ROOT):
+for p in (HERE, os.path.dirname(HERE), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 import ref_harness as H  # noqa: E402
+import scenario_fuzz as S  # noqa: E402
 
-_goals = None
+FIELDS = S.FIELDS
 
 
-def goals():
-    global _goals
-    if _goals is None:
+class ReferenceBackend:
+    """gym.make('IGLUGridworld-v0', ...) of the imported Python reference (through ref_harness' shims)."""
+    name = 'reference'
+    float32_actions = False      # the reference takes Python floats: raw doubles are drawn for a fifth of the scenarios
+
+    def __init__(self):
+        self.gym, self.Task, _ = H.load_reference()
+        from gridworld.tasks.task import Subtasks
+        from gridworld.tasks.task_set import CustomTasks, RandomTasks
+        self.Subtasks, self.CustomTasks, self.RandomTasks = Subtasks, CustomTasks, RandomTasks
         g = H.load_cdm_goals()
-        _goals = [g[k] for k in sorted(g, key=lambda n: int(n[1:]))]
-    return _goals
+        self._goals = [g[k] for k in sorted(g, key=lambda n: int(n[1:]))]
+
+    def make(self, kw):
+        return self.gym.make('IGLUGridworld-v0', vector_state=True, render=False, **kw)
+
+    def goals(self):
+        return self._goals
+
+    def trig(self, crlibm):
+        """glibc (CPython's math), or correctly rounded mpmath trig patched into gridworld.core.world"""
+        return H.cr_libm() if crlibm else contextlib.nullcontext()
+
+    def oracle_device_trig(self, crlibm):
+        return bool(crlibm)      # correctly rounded reference <-> the product's own sincos / atan2 on the oracle's side
+
+    def internals(self, env):
+        return H._internals(env)
+
+    def syn(self, env):
+        s = env.unwrapped._synthetic_task
+        return int(s.max_int), int(s.prev_grid_size)
 
 
-# ------------------------------------------------------------------------------------------------ scenario pieces
-def rt20(rng):
-    g = np.zeros((9, 11, 11), np.int8)
-    bx, bz = rng.randint(2, 9, size=2)
-    cells = [(bx + dx, bz + dz) for dx in range(-2, 3) for dz in range(-2, 3)]
-    for i in rng.permutation(25)[:rng.randint(1, 21)]:
-        g[0, cells[i][0], cells[i][1]] = rng.randint(1, 7)
-    return g
+_backend = None
 
 
-def scattered(rng, n, levels=9):
-    g = np.zeros((levels * 121,), np.int8)
-    g[rng.permutation(g.size)[:n]] = rng.randint(1, 7, size=n)
-    out = np.zeros((9, 11, 11), np.int8)
-    out.reshape(-1)[:g.size] = g
-    return out
-
-
-def draw_target(rng):
-    k = rng.randint(8)
-    if k == 0:
-        return rt20(rng)
-    if k == 1:
-        return scattered(rng, rng.randint(1, 41))
-    if k in (2, 3):
-        return goals()[rng.randint(len(goals()))].copy()
-    if k == 4:      # a few low levels, denser (towers, walls)
-        return scattered(rng, rng.randint(5, 80), levels=rng.randint(1, 4))
-    if k == 5:      # DUMMY_TASK's target (tasks/task_set.py:160)
-        g = np.zeros((9, 11, 11), np.int8)
-        g[8, 10, 10] = 1
-        return g
-    if k == 6:      # one or two blocks near the spawn point: completions happen
-        g = np.zeros((9, 11, 11), np.int8)
-        for _ in range(rng.randint(1, 3)):
-            g[0, rng.randint(4, 7), rng.randint(3, 6)] = rng.randint(1, 7)
-        return g
-    return np.zeros((9, 11, 11), np.int8) if rng.rand() < 0.3 else rt20(rng)
-
-
-def draw_start(rng, target):
-    """sparse starting grid: [], a subset of the target, foreign blocks, or a wide one-colour floor."""
-    k = rng.randint(6)
-    sp = H.dense_to_sparse(target)
-    if k <= 1 or (k == 2 and not sp):
-        return []
-    out = []
-    if k in (2, 3):
-        m = rng.randint(0, len(sp) + 1)
-        out = [sp[i] for i in rng.permutation(len(sp))[:m]]
-    if k in (3, 4):
-        for _ in range(rng.randint(1, 6)):
-            x, y, z = int(rng.randint(-5, 6)), int(rng.randint(-1, 4)), int(rng.randint(-5, 6))
-            if not any(b[:3] == (x, y, z) for b in out):
-                c = int(rng.randint(1, 7))
-                if target[y + 1, x + 5, z + 5] == c and rng.rand() < 0.5:
-                    continue
-                out.append((x, y, z, c))
-    if k == 5:      # many blocks of one colour -> negative inventory (env.py:243-246)
-        c = int(rng.randint(1, 7))
-        n = int(rng.randint(15, 60))
-        cells = [(x, -1, z) for x in range(-5, 6) for z in range(-5, 6)]
-        out = [(*cells[i], c) for i in rng.permutation(121)[:n]]
-    return out
-
-
-def draw_pose(rng):
-    q = rng.rand() < 0.4
-    x, z = rng.uniform(-9, 9, size=2)
-    y = rng.uniform(-0.25, 8.5)
-    yaw = rng.uniform(0, 360)
-    pitch = rng.uniform(-90, 90)
-    if q:
-        x, y, z = round(x * 4) / 4, round(y * 4) / 4 - 0.25, round(z * 4) / 4
-        yaw, pitch = float(5 * int(yaw / 5)), float(5 * int(pitch / 5))
-    return [float(x), float(y), float(z), float(yaw), float(pitch)]
-
-
-def structure_seq(rng, dense, n_turns):
-    blocks = H.dense_to_sparse(dense)
-    if not blocks:
-        blocks = [(0, -1, 0, 1)]
-    order = sorted(range(len(blocks)), key=lambda i: (blocks[i][1], rng.rand()))
-    blocks = [blocks[i] for i in order]
-    n_turns = max(1, min(n_turns, len(blocks)))
-    cuts = sorted(set(int(round(len(blocks) * (k + 1) / n_turns)) for k in range(n_turns)))
-    return [blocks[:c] for c in cuts if c > 0]
-
-
-WALK_BUILDER_P = np.array([2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 2, 2, 4, 1, 3, 8], np.float64)
-
-
-def draw_kwargs(rng):
-    space = ('walking', 'walking_dict', 'flying')[rng.choice(3, p=[0.4, 0.25, 0.35])]
-    kw = dict(size_reward=bool(rng.rand() < 0.5), select_and_place=bool(rng.rand() < 0.7),
-              right_placement_scale=[1, 2., 0.5, 1.5][rng.randint(4)],
-              wrong_placement_scale=[0.1, 1., 0.25, 0.][rng.randint(4)],
-              max_steps=int([7, 30, 100, 250, 1000][rng.randint(5)]))
-    if space == 'flying':
-        kw['action_space'] = 'flying'
-    elif space == 'walking_dict':
-        kw['discretize'] = False
-    return space, kw
-
-
-class ActionSource:
-    """One scenario's action stream (as the reference takes it) plus the same action for the oracle."""
-
-    def __init__(self, rng, space):
-        self.rng, self.space = rng, space
-        self.builder = rng.rand() < 0.5
-        self.raw_f64 = rng.rand() < 0.2       # continuous values as raw doubles instead of widened float32
-        self.zero_p = rng.choice([0.0, 0.1, 0.4])
-
-    def _cont(self, lo, hi, n):
-        v = self.rng.uniform(lo, hi, size=n)
-        if not self.raw_f64:
-            v = v.astype(np.float32).astype(np.float64)
-        z = self.rng.rand(n) < self.zero_p
-        v[z] = 0.0
-        if self.rng.rand() < 0.05:
-            v[self.rng.randint(n)] = [lo, hi][self.rng.randint(2)]
-        return [float(x) for x in v]
-
-    def draw(self):
-        rng = self.rng
-        if self.space == 'walking':
-            a = int(rng.choice(18, p=WALK_BUILDER_P / WALK_BUILDER_P.sum())) if self.builder else int(rng.randint(18))
-            return a, a
-        if self.space == 'walking_dict':
-            p = 0.35 if self.builder else 0.2
-            b = [int(v) for v in (rng.rand(7) < p)]
-            hot = int(rng.randint(0, 7)) if rng.rand() < 0.3 else 0
-            cam = self._cont(-5, 5, 2)
-            if self.builder and rng.rand() < 0.3:
-                cam[1] = -abs(cam[1])   # pitch up is negative-looking-down? keep variety either way
-            ref = {'forward': b[0], 'back': b[1], 'left': b[2], 'right': b[3], 'jump': b[4], 'attack': b[5],
-                   'use': b[6], 'hotbar': hot, 'camera': cam}
-            return ref, {'buttons': b + [hot], 'camera': cam}
-        mv = self._cont(-1, 1, 3)
-        cam = self._cont(-5, 5, 2)
-        inv = int(rng.randint(7))
-        pl = int(rng.choice(3, p=[0.2, 0.5, 0.3])) if self.builder else int(rng.randint(3))
-        a = {'movement': mv, 'camera': cam, 'inventory': inv, 'placement': pl}
-        return a, a
-
-
-# ------------------------------------------------------------------------------------------------ one scenario
-FIELDS = ('agentPos', 'compass', 'inventory', 'grid', 'reward', 'done', 'internal', 'syn_max_int',
-          'syn_prev_size', 'env_max_int', 'step_no')
-
-
-def _b32(a):
-    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
-
-
-def _b64(a):
-    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
-
-
-def _push_task(env, orc):
-    """Hands the task the reference env currently holds (and its effective starting grid) to the oracle."""
-    u = env.unwrapped
-    task = u._task
-    start = u.starting_grid if u.starting_grid is not None else []
-    full = getattr(task, 'full_grid', None)
-    invariant = len(task.admissible) == 4                      # tasks/task.py:58-59: [[(0, 0)]] otherwise
-    orc.set_task(np.asarray(task.target_grid), [tuple(int(v) for v in b) for b in start],
-                 None if full is None else np.asarray(full), invariant=invariant)
+def backend():
+    global _backend
+    if _backend is None:
+        _backend = ReferenceBackend()
+    return _backend
 
 
 def run_scenario(seed, max_T=None):
-    """Returns dict(steps, resets, mismatch=None | {...}, tags...)."""
-    from oracle import oracle as O
-    gym, Task, Tasks = H.load_reference()
-    from gridworld.tasks.task import Subtasks
-    from gridworld.tasks.task_set import CustomTasks, RandomTasks
-    rng = np.random.RandomState(seed)
-    np.random.seed((seed * 7919 + 13) % (2 ** 32))            # the reference's generators use the global stream
-    space, kw = draw_kwargs(rng)
-    continuous = space != 'walking'
-    crlibm = bool(rng.rand() < (0.35 if continuous else 0.1))
-    source = ('task', 'subtasks', 'custom', 'random')[rng.choice(4, p=[0.55, 0.15, 0.15, 0.15])]
-    T = int(rng.randint(60, 400))
-    if crlibm:
-        T = min(T, 200)                                        # mpmath trig is slow
-    if max_T:
-        T = min(T, max_T)
-    info = dict(seed=int(seed), space=space, source=source, crlibm=crlibm, kwargs=kw, T=T)
-    okw = {k: v for k, v in kw.items()}
-    orc = O.OracleEnv(**okw)
-    O.use_device_trig(crlibm)
-    ctx = H.cr_libm() if crlibm else None
-    if ctx:
-        ctx.__enter__()
-    try:
-        with warnings.catch_warnings():
-            warnings.simplefilter('ignore')
-            env = gym.make('IGLUGridworld-v0', vector_state=True, render=False, **kw)
-            pose = None
-            if source == 'task':
-                target = draw_target(rng)
-                start = draw_start(rng, target)
-                tkw = {}
-                if rng.rand() < 0.2:
-                    full = target.copy()
-                    extra = rng.permutation(1089)[:rng.randint(1, 8)]
-                    f = full.reshape(-1)
-                    f[extra] = np.where(f[extra] == 0, rng.randint(1, 7, size=len(extra)), f[extra])
-                    tkw['full_grid'] = full.astype(np.int32)
-                if rng.rand() < 0.2:
-                    tkw['invariant'] = False
-                env.set_task(Task('chat', target.astype(np.int32), starting_grid=start, **tkw))
-            elif source == 'subtasks':
-                seq = structure_seq(rng, draw_target(rng), int(rng.randint(1, 6)))
-                dialog = [['<A> turn %d' % i, '<B> ok'] for i in range(len(seq))]
-                env.set_task_generator(Subtasks(dialog, seq))
-            elif source == 'custom':
-                n = int(rng.randint(1, 5))
-                tg = [draw_target(rng) for _ in range(n)]
-                goals_ = [('c%d' % i, H.dense_to_sparse(g) if (rng.rand() < 0.3 and g.any()) else g.astype(np.int32))
-                          for i, g in enumerate(tg)]
-                tkw = {'starting_grid': draw_start(rng, tg[0])}
-                if rng.rand() < 0.3:
-                    tkw['invariant'] = False
-                env.set_task_generator(CustomTasks(goals_, task_kwargs=tkw))
-            else:
-                d = int(rng.randint(1, 4))
-                gen = RandomTasks(max_blocks=int(rng.randint(1, min(6, (d + 1) ** 2) + 1)),
-                                  height_levels=int(rng.randint(1, 4)), max_dist=d,
-                                  num_colors=int(rng.randint(1, 7)), max_cache=int(rng.choice([0, 0, 3])))
-                env.set_task_generator(gen)
-                pose = [0., 0., 0., 0., 0.] if rng.rand() < 0.5 else draw_pose(rng)
-            if pose is None and rng.rand() < 0.25:
-                pose = draw_pose(rng)
-            if pose is not None:
-                # RandomTasks' tasks have starting_grid None (step() would raise, env.py:290): they need the
-                # overwrite; for the others it replaces the task's own starting grid
-                u = env.unwrapped
-                base = u._task.target_grid if source != 'random' else np.zeros((9, 11, 11), np.int8)
-                ow = draw_start(rng, np.asarray(base)) if (source == 'random' or rng.rand() < 0.5) \
-                    else list(u.starting_grid or [])
-                env.initialize_world(ow, pose)
-                orc.set_initial_pose(pose)
-            info['pose'] = pose
-            acts = ActionSource(rng, space)
-            steps = resets = 0
-
-            def check(field, ok, t, detail):
-                if not ok:
-                    raise _Mismatch(dict(field=field, step=t, detail=detail))
-
-            def do_reset(t):
-                nonlocal resets
-                obs = env.reset()
-                _push_task(env, orc)
-                o = orc.reset()
-                resets += 1
-                check('reset.inventory', np.array_equal(obs['inventory'], o['inventory']), t,
-                      [obs['inventory'].tolist(), o['inventory'].tolist()])
-                check('reset.grid', np.array_equal(obs['grid'], o['grid']), t, 'grid')
-                check('reset.agentPos', np.array_equal(_b32(obs['agentPos']), _b32(o['agentPos'])), t, 'agentPos')
-                check('reset.compass', np.array_equal(_b32(obs['compass']), _b32(o['compass'])), t, 'compass')
-                check('reset.internal', np.array_equal(_b64(H._internals(env)), _b64(orc.internal())), t,
-                      [H._internals(env), orc.internal().tolist()])
-                st = orc.task_state()
-                check('reset.env_max_int', int(env.unwrapped.max_int) == st['env_max_int'], t,
-                      [int(env.unwrapped.max_int), st['env_max_int']])
-                check('reset.syn_max_int', int(env.unwrapped._synthetic_task.max_int) == st['syn_max_int'], t, '')
-
-            try:
-                do_reset(0)
-                done = False
-                for t in range(T):
-                    if done:
-                        do_reset(t)
-                    ra, oa = acts.draw()
-                    obs, reward, done, _ = env.step(ra)
-                    o, orew, odone, _ = orc.step(oa)
-                    steps += 1
-                    u = env.unwrapped
-                    check('done', bool(done) == bool(odone), t, [bool(done), bool(odone)])
-                    check('reward', float(reward) == float(orew), t, [float(reward), float(orew)])
-                    check('grid', np.array_equal(obs['grid'], o['grid']), t, 'grid')
-                    check('inventory', np.array_equal(obs['inventory'], o['inventory']), t,
-                          [obs['inventory'].tolist(), o['inventory'].tolist()])
-                    check('agentPos', np.array_equal(_b32(obs['agentPos']), _b32(o['agentPos'])), t,
-                          [obs['agentPos'].tolist(), o['agentPos'].tolist()])
-                    check('compass', np.array_equal(_b32(obs['compass']), _b32(o['compass'])), t,
-                          [obs['compass'].tolist(), o['compass'].tolist()])
-                    ri, oi = H._internals(env), orc.internal()
-                    check('internal', np.array_equal(_b64(ri), _b64(oi)), t, [ri, oi.tolist()])
-                    st = orc.task_state()
-                    syn = u._synthetic_task
-                    check('syn_max_int', int(syn.max_int) == st['syn_max_int'], t, [int(syn.max_int), st['syn_max_int']])
-                    check('syn_prev_size', int(syn.prev_grid_size) == st['syn_prev_size'], t,
-                          [int(syn.prev_grid_size), st['syn_prev_size']])
-                    check('env_max_int', int(u.max_int) == st['env_max_int'], t, [int(u.max_int), st['env_max_int']])
-                    check('step_no', int(u.step_no) == st['step_no'], t, [int(u.step_no), st['step_no']])
-                info['mismatch'] = None
-            except _Mismatch as m:
-                info['mismatch'] = m.args[0]
-            info.update(steps=steps, resets=resets)
-    finally:
-        if ctx:
-            ctx.__exit__(None, None, None)
-        O.use_device_trig(False)
-    return info
-
-
-class _Mismatch(Exception):
-    pass
+    return S.run_scenario(seed, backend(), max_T)
 
 
 def _worker(args):
     seed, max_T = args
-    try:
-        return run_scenario(seed, max_T)
-    except Exception as e:  # a crash of either side is a finding, not a reason to lose the run
-        import traceback
-        return dict(seed=int(seed), steps=0, resets=0, mismatch=dict(field='exception', step=-1,
-                                                                     detail=traceback.format_exc()[-1500:]),
-                    space='?', source='?', crlibm=False)
-
-
-def summarize(results, wall):
-    by = {}
-    for r in results:
-        for key in ('space:' + r['space'], 'source:' + r['source'], 'trig:' + ('cr_libm' if r['crlibm'] else 'glibc')):
-            d = by.setdefault(key, dict(scenarios=0, steps=0, mismatches=0))
-            d['scenarios'] += 1
-            d['steps'] += r['steps']
-            d['mismatches'] += r['mismatch'] is not None
-    bad = [r for r in results if r['mismatch'] is not None]
-    return dict(scenarios=len(results), reference_env_steps=int(sum(r['steps'] for r in results)),
-                resets=int(sum(r['resets'] for r in results)), mismatches=len(bad), by=by,
-                first_mismatches=bad[:10], wall_s=round(wall, 1),
-                compared_every_step=list(FIELDS))
+    return S.run_scenario_safe(seed, backend(), max_T)
 
 
 def run(seeds, procs=1, max_T=None, progress=None):
@@ -413,7 +119,7 @@ def run(seeds, procs=1, max_T=None, progress=None):
                     b = sum(x['mismatch'] is not None for x in results)
                     print(f'{i + 1}/{len(jobs)} scenarios, {s} steps, {b} mismatches, {time.time() - t0:.0f} s',
                           flush=True)
-    return summarize(results, time.time() - t0)
+    return S.summarize(results, time.time() - t0)
 
 
 def main():

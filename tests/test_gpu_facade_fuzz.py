@@ -1,0 +1,28 @@
+"""The product's 1-env gym facade against the CPU oracle on the SAME random scenarios the Python reference was run on
+(tests/scenario_fuzz.py; reference side: tests/golden/fuzz_ref_vs_oracle.py, 18.5 M reference env-steps logged under
+profiles/).  A scenario draws create_env kwargs, a task source -- Task, or Subtasks / CustomTasks / RandomTasks with
+seeded np.random, which gridworld_amd.tasks consumes exactly as the reference's generators do --, starting grids,
+full_grid, initialize_world poses, one of the three action spaces and an action mix; the facade
+(gridworld_amd.make('IGLUGridworld-v0', ...): SizeReward(GridWorld) on the HIP path) and an OracleEnv are stepped in
+lock-step and every observation, reward (the Python value), done, float64 internal (env.unwrapped.agent), task
+counter, GridWorld.max_int and step_no must agree on every step, every reset observation too.  Seeds 1,000,000+ are
+the first scenarios of the logged reference run: what both sides agree with the oracle on, they agree on with each
+other."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_facade_vs_oracle_on_the_reference_fuzz_scenarios():
+    import scenario_fuzz as S
+    s = S.run(range(1000000, 1000160), S.ProductBackend(), max_T=150)
+    assert s['scenarios'] == 160 and s['env_steps'] > 12000 and s['resets'] > 300
+    assert s['mismatches'] == 0, s['first_mismatches'][:2]
+    for key in ('space:walking', 'space:walking_dict', 'space:flying', 'source:task', 'source:subtasks',
+                'source:custom', 'source:random'):
+        assert s['by'][key]['steps'] > 0, key
+    print('\nfacade vs oracle:', {k: s[k] for k in ('scenarios', 'env_steps', 'resets', 'mismatches', 'wall_s')})

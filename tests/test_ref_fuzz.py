@@ -19,7 +19,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir('/root/reference'),
 def test_reference_vs_oracle_200_scenarios():
     sys.path.insert(0, os.path.join(HERE, 'golden'))
     import fuzz_ref_vs_oracle as F
-    s = F.run(range(77000, 77200), procs=min(4, os.cpu_count() or 1), max_T=150)
+    s = F.run(range(77000, 77200), procs=min(4, os.cpu_count() or 1), max_T=150)   # (scenario generator: tests/scenario_fuzz.py)
     assert s['scenarios'] == 200 and s['reference_env_steps'] > 15000
     assert s['mismatches'] == 0, s['first_mismatches'][:2]
     # every scenario family was drawn
