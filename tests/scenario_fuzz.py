@@ -408,3 +408,21 @@ def run(seeds, backend, max_T=None):
     t0 = time.time()
     results = [run_scenario_safe(int(s), backend, max_T) for s in seeds]
     return summarize(results, time.time() - t0)
+
+
+if __name__ == '__main__':   # product side on the GPU box: python tests/scenario_fuzz.py [scenarios] [seed0] [out.json]
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 160
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+    s = run(range(seed0, seed0 + n), ProductBackend())
+    s.update(seed0=seed0, backend='product: gridworld_amd.make(...) on the GPU vs oracle.OracleEnv (device-trig mode)',
+             command=' '.join(sys.argv))
+    s.pop('reference_env_steps', None)
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], 'w') as f:
+            json.dump(s, f, indent=1)
+    print(json.dumps({k: v for k, v in s.items() if k not in ('by', 'first_mismatches')}))
+    sys.exit(1 if s['mismatches'] else 0)
