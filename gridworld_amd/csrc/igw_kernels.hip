@@ -1976,7 +1976,7 @@ int igw_version(void) { return IGW_VERSION; }
 #define IGW_BUILD_ID "igw-build-id:unstamped"
 #endif
 // (the string carries a marker so that build.py can read the id of a library file without loading it)
-const char* igw_build_id(void) { return IGW_BUILD_ID + sizeof("igw-build-id:") - 1; }
+const char* igw_build_id(void) { return &IGW_BUILD_ID[sizeof("igw-build-id:") - 1]; }
 const char* igw_last_error(void) { return g_err; }
 
 int igw_device_count(void) {
