@@ -21,3 +21,5 @@ run sq_insts --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 run sq_cycles --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run sq_misc --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM
 python3 tools/summarize_profile.py $OUT $TAG
+# the raw rocprofv3 trees are tens of MB per workload (gpurun merges at most 64 MiB back): keep them only on request
+if [ -z "${KEEP_RAW:-}" ]; then rm -rf $OUT/*/; fi
