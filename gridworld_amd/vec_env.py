@@ -469,6 +469,13 @@ class VecGridWorld:
         self._children.extend(subs)
         return subs
 
+    def _release_children(self, subs):
+        """Sub-batches that are no longer needed: their counters move into this env's own buffer."""
+        for c in subs:
+            if c in self._children:
+                self.stats_buf += c.stats_buf
+                self._children.remove(c)
+
     # ---- introspection ----
     def stats_tensor(self):
         """The device counters [8] int64 of this env and its sub-batches as a DEVICE tensor (no synchronisation)."""
@@ -579,6 +586,16 @@ class StepGraph:
         if record:
             f = self.outs.view(torch.float32)
             self.rewards, self.dones = f[:, :, 12], self.outs[:, :, 52]
+
+    def __del__(self):
+        # the chains' contexts were registered with the env for its counters: fold their counts into the env's own
+        # buffer and let them go (a bench that captures many graphs must not accumulate contexts)
+        subs, env = getattr(self, 'subs', None), getattr(self, 'env', None)
+        if subs and env is not None:
+            try:
+                env._release_children(subs)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
 
     def replay(self):
         env = self.env
