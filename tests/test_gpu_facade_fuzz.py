@@ -1,5 +1,5 @@
 """The product's 1-env gym facade against the CPU oracle on the SAME random scenarios the Python reference was run on
-(tests/scenario_fuzz.py; reference side: tests/golden/fuzz_ref_vs_oracle.py, 18.5 M reference env-steps logged under
+(tests/scenario_fuzz.py; reference side: tests/golden/fuzz_ref_vs_oracle.py, 31.3 M reference env-steps logged under
 profiles/).  A scenario draws create_env kwargs, a task source -- Task, or Subtasks / CustomTasks / RandomTasks with
 seeded np.random, which gridworld_amd.tasks consumes exactly as the reference's generators do --, starting grids,
 full_grid, initialize_world poses, one of the three action spaces and an action mix; the facade
