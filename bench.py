@@ -71,10 +71,15 @@ def parse_args(argv=None):
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--lanes-per-env', type=int, default=0)
     ap.add_argument('--seed', type=int, default=2024)
-    ap.add_argument('--windows', type=int, default=7, help='complete measured windows; value = their median')
+    ap.add_argument('--windows', type=int, default=15, help='complete measured windows; value = their median')
     ap.add_argument('--rehearsals', type=int, default=3,
                     help='passes through the whole W + K sequence before the measured windows (reported, not counted)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-scale', type=float, default=1.0,
+                    help='scales the CPU baseline\'s bounded samples (1.0 = about 25 s of CPU work; tests use 0.05)')
+    ap.add_argument('--sweep', default='131072,262144,524288,2097152',
+                    help='envs-per-GPU sizes of config.sweep (default single-GPU run); the largest one >= 2,097,152 is also '
+                         'config.large, the batch whose per-step working set exceeds the 256 MB Infinity Cache; "" = none')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--no-async', action='store_true', help='(kept for old command lines; the two-sub-batch figure needs --async now)')
     ap.add_argument('--async', dest='do_async', action='store_true',
@@ -537,9 +542,10 @@ class Runner:
         if not self.args.lockstep:
             self.busy(0.3, 0)
         rehearsal_ms = [round(1e3 * self.window()[0] / K, 5) for _ in range(rehearsals)]
-        walls, kernels, ps, resets, cells, counted = [], [], [], [], [], []
+        walls, kernels, ps, resets, cells, counted, timelines = [], [], [], [], [], [], []
         for _ in range(max(1, windows)):
             el, st0_dev, kms, host_tl = self.window()
+            timelines.append(host_tl)
             s0, s1 = st0_dev.cpu(), env.stats_tensor().cpu()
             walls.append(el)
             kernels.append(kms)
@@ -555,9 +561,22 @@ class Runner:
         walls_max = gdist.reduce_windows(walls, self.device)
         med = statistics.median(walls_max)
         i_med = min(range(len(walls_max)), key=lambda i: abs(walls_max[i] - med))
+        srt = sorted(walls_max)
+        pct = lambda q: srt[min(len(srt) - 1, max(0, int(round(q * (len(srt) - 1)))))]   # noqa: E731
+        i_max = max(range(len(walls_max)), key=lambda i: walls_max[i])
+        names = ('head_launches', 'graph_launch', 'event_record', 'spin', 'synchronize', 'barrier')
         return {'elapsed': med, 'windows_ms_per_step': [round(1e3 * w / K, 5) for w in walls_max],
                 'windows_kernel_us': [round(1e3 * k, 3) for k in kernels],
                 'window_spread': (max(walls_max) - min(walls_max)) / med,
+                'window_p10_ms_per_step': 1e3 * pct(0.1) / K, 'window_p90_ms_per_step': 1e3 * pct(0.9) / K,
+                'window_spread_p10_p90': (pct(0.9) - pct(0.1)) / med,
+                # where the host spent the slowest and the median window of THIS rank (us): an outlier window shows
+                # up either in its kernels (windows_kernel_us) or in one of these host segments
+                'slowest_window': {'index': i_max, 'ms_per_step': round(1e3 * walls_max[i_max] / K, 5),
+                                   'kernel_us': round(1e3 * kernels[i_max], 3),
+                                   'host_us': {n: round(1e6 * x, 1) for n, x in zip(names, timelines[i_max])}},
+                'median_window': {'index': i_med, 'kernel_us': round(1e3 * kernels[i_med], 3),
+                                  'host_us': {n: round(1e6 * x, 1) for n, x in zip(names, timelines[i_med])}},
                 'rehearsal_ms_per_step': rehearsal_ms,
                 'kernel_ms': statistics.median(kernels), 'p_changed': ps[i_med], 'p_cell_changed': cells[i_med],
                 'resets_in_window': resets[i_med], 'steps_counted': counted[i_med], 'steps_counted_all': counted}
@@ -741,8 +760,8 @@ def run(args):
     # is computed from their sum, and the sum must be what the launches were asked to do.
     steps_per_rank, gather_via = gdist.gather_counts_rccl(m['steps_counted'], device)
     total_steps = sum(steps_per_rank)
-    if args.debug_flags:   # (diagnostic build, timing-only ablations: some switches end the kernel before it counts)
-        total_steps = N * K * world
+    if args.debug_flags or os.environ.get('IGW_AB_NO_STEP_COUNTER'):   # (diagnostic build, timing-only ablations: some switches end the
+        total_steps = N * K * world                                     # kernel before it counts; tools/ab_variants.sh: the -DIGW_STEPS_MODE=0 variant)
     elif any(c != N * K for c in m['steps_counted_all']) or total_steps != N * K * world:
         raise SystemExit(f'device step counters disagree with the launches: windows {m["steps_counted_all"]}, '
                          f'per rank {steps_per_rank}, expected {N * K} per rank and window')
@@ -924,6 +943,9 @@ def run(args):
                    'value_is': 'median of %d complete windows (W warm-up steps, barrier + synchronize, K timed steps, '
                                'synchronize + barrier; max over ranks per window)' % len(m['windows_ms_per_step']),
                    'windows_ms_per_step': m['windows_ms_per_step'], 'window_spread': m['window_spread'],
+                   'window_p10_ms_per_step': m['window_p10_ms_per_step'], 'window_p90_ms_per_step': m['window_p90_ms_per_step'],
+                   'window_spread_p10_p90': m['window_spread_p10_p90'],
+                   'slowest_window': m['slowest_window'], 'median_window': m['median_window'],
                    'windows_kernel_us': m['windows_kernel_us'],
                    'episodes': 'lock-step' if args.lockstep else 'de-synchronised (random episode phase + pre-roll)',
                    'setup': 'untimed: task upload, pre-roll of >= 250 steps with fresh random actions (steady state), graph '

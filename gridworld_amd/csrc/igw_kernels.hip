@@ -67,6 +67,16 @@ __device__ inline void stamp_features(const KParams&, unsigned long long) {}
 // because a flat access may alias LDS, puts an s_waitcnt vmcnt(0) in front of it whenever global stores are in flight:
 // at the end of a step that waited for the acknowledgement of every store of the wavefront (histogram rows, records) --
 // 700 cycles on every wavefront with something to count.
+// IGW_STEPS_MODE: how a step launch adds its env-steps to IGW_STAT_STEPS (2: once per launch; 1: once per block --
+// round 5; 0: not at all -- round 4; the other two exist for the same-box A/B of tools/ab_variants.sh)
+// IGW_SPLIT_BURST: the step kernel waits for its small input loads first and for the occupancy pieces behind the
+// action parse / trig (see step_kernel); 0 = one wait for the whole burst (rounds 3-5)
+#ifndef IGW_SPLIT_BURST
+#define IGW_SPLIT_BURST 0
+#endif
+#ifndef IGW_STEPS_MODE
+#define IGW_STEPS_MODE 2
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) unsigned long long global_u64;
 __device__ inline void counter_add(unsigned long long* p, unsigned long long v) {
@@ -1227,11 +1237,21 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
     const auto counters = [&]() {   // one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
         const uint64_t m_need = __ballot(need && active && G.gl == 0), m_cell = __ballot(ch.idx >= 0 && active && G.gl == 0),
                        m_reset = __ballot(do_reset && G.gl == 0);
-        // IGW_STAT_STEPS: the env-steps of the block, added once per block by its first wavefront (scalar condition) --
-        // the device-side count of the work a launch did (bench.py gathers its per-rank delta over RCCL)
-        if (((m_need | m_cell | m_reset) != 0 || wave == 0) && tp.stats != nullptr && G.lane == 0) {
+        // IGW_STAT_STEPS: the env-steps of the launch -- the device-side count of the work a launch did (bench.py gathers
+        // its per-rank delta over RCCL).  Added ONCE PER LAUNCH, by the first wavefront of block 0 (a scalar condition;
+        // n_envs is read from the kernarg segment inside the branch).  Round 5 added it once per BLOCK: the first
+        // wavefront of every block then always took this branch -- 1,024 atomics per 65,536-env launch, sixteen to a
+        // stripe -- and the launch was 1-2 % slower (same-box A/B: profiles/r06_ab_variants.txt).
+#if IGW_STEPS_MODE == 2
+        const bool count_steps = wave == 0 && blockIdx.x == 0;
+#elif IGW_STEPS_MODE == 1
+        const bool count_steps = wave == 0;
+#else
+        const bool count_steps = false;
+#endif
+        if (((m_need | m_cell | m_reset) != 0 || count_steps) && tp.stats != nullptr && G.lane == 0) {
             unsigned long long* st = tp.stats + (blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8;
-            if (wave == 0) counter_add(st + IGW_STAT_STEPS, (unsigned long long)block_envs);
+            if (count_steps) counter_add(st + IGW_STAT_STEPS, (unsigned long long)(IGW_STEPS_MODE == 2 ? p.n_envs : block_envs));
             if (m_need) counter_add(st + IGW_STAT_CHANGED, (unsigned long long)__builtin_popcountll(m_need));
             if (m_cell) counter_add(st + IGW_STAT_RESCANS, (unsigned long long)__builtin_popcountll(m_cell));
             if (m_reset) counter_add(st + IGW_STAT_RESETS, (unsigned long long)__builtin_popcountll(m_reset));
@@ -1339,7 +1359,9 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // Every load the step needs before it can compute -- occupancy row, agent record, task index, action -- is
     // issued before the first wait: one memory round trip.
     OccStage<GS> occ_in = {};
+#if !IGW_SPLIT_BURST
     if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);  // diag 32: what the occupancy rows cost in the load burst
+#endif
     // The agent record: with four or more lanes per env, lane q of a quad fetches the 16-byte piece q and the quad
     // hands the pieces round by DPP after the wait -- ONE dwordx4 per lane instead of four.  (All four lanes reading
     // the whole record is one cache line per env either way, but the CU's address pipe handles a wavefront's
@@ -1364,8 +1386,25 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     if constexpr (FLY_SPREAD) load_fly_spread<GS>(ah, env_r, G.gl, ra);
     else ra = load_action<MODE>(ah, env_r);
     int8_t* grid_g = p.grid + (size_t)env_r * STRIDE;
+#if IGW_SPLIT_BURST
+    // Split burst (four-lane groups): the SMALL loads (agent record piece, aux word, action: 24-28 bytes per lane) are
+    // issued FIRST and waited for alone -- loads return in order, so s_waitcnt vmcnt(3) -- and the record unpack, the
+    // action parse and the camera / heading arithmetic run while the three occupancy pieces (48 bytes per lane, 70 % of
+    // the burst) are still on their way; the occupancy words go to LDS behind world_act_pre, in front of the ray march.
+    if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);
+#endif
     occ_commit_const<GS>(occ_wave_s);   // (LDS writes that need no load: in the shadow of the burst)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && IGW_SPLIT_BURST
+    if constexpr (GS == 4) {   // the first wait: the small loads only
+        if constexpr (MODE == MODE_WALK)
+            asm volatile("" : "+v"(aux_w), "+v"(ra.action), "+v"(rec_piece.x), "+v"(rec_piece.y), "+v"(rec_piece.z), "+v"(rec_piece.w));
+        else if constexpr (MODE == MODE_FLY)
+            asm volatile("" : "+v"(aux_w), "+v"(ra.w1), "+v"(ra.w2), "+v"(rec_piece.x), "+v"(rec_piece.y), "+v"(rec_piece.z), "+v"(rec_piece.w));
+        else
+            asm volatile("" : "+v"(aux_w), "+v"(ra.buttons.x), "+v"(ra.buttons.y), "+v"(ra.f[3]), "+v"(ra.f[4]), "+v"(rec_piece.x), "+v"(rec_piece.y), "+v"(rec_piece.z), "+v"(rec_piece.w));
+    }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !IGW_SPLIT_BURST
     // ... and ONE wait: the empty statement below takes a register of every load above as an operand, and the
     // occupancy words as in-out operands, so every load is issued before it and the LDS writes of the occupancy row
     // come after it.  (Without it the compiler waited for the occupancy row, wrote it to LDS, and only then issued
@@ -1381,7 +1420,8 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
             asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(aux_w), "v"(ra.buttons.x), "v"(ra.f[3]), "v"(ra.f[4]), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
     }
 #endif
-    occ_commit_var<GS>(G, occ_in, occ_s);
+    constexpr bool SPLIT = IGW_SPLIT_BURST && GS == 4;   // (the occupancy words go to LDS behind world_act_pre)
+    if constexpr (!SPLIT) occ_commit_var<GS>(G, occ_in, occ_s);
     if constexpr (REC_SPREAD) {  // piece 0: x, y | 1: z, yaw | 2: pitch, vy | 3: inventory, step_no, pack (include/igw.h)
         uint32_t w[16];
         const int px = (int)rec_piece.x, py = (int)rec_piece.y, pz = (int)rec_piece.z, pw = (int)rec_piece.w;
@@ -1408,12 +1448,12 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // (the lanes that do not prefetch: tail_step loads for them if it has to.  Their registers hold "any value", and the
     // cheapest any value is one that is already in registers and dead: the words of the input burst)
     ResetMeta pre = reset_meta_any();
-    if constexpr (GS == 4 && REC_SPREAD) {
+    if constexpr (GS == 4 && REC_SPREAD && !SPLIT) {
         const auto as4 = [](const uint4& v) { return vu4{v.x, v.y, v.z, v.w}; };
         pre = ResetMeta{as4(rec_piece), as4(occ_in.v[0]), as4(occ_in.v[1]), as4(occ_in.v[2])};
     }
     if (pre_ok) pre = load_reset_meta(p.task_meta + task);
-    wave_sync();
+    if constexpr (!SPLIT) wave_sync();
     stamp(p, 1);
     if (IGW_DIAG_FLAG(p, 128)) return;  // diag 128: launch + the input burst, nothing else
     // a wave with an episode running out in this step has the reset to do on top: one priority level up
@@ -1462,6 +1502,10 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
         return;
     }
 #endif
+    if constexpr (SPLIT) {   // the occupancy pieces have had the record unpack, the action parse and the step's trig to arrive
+        occ_commit_var<GS>(G, occ_in, occ_s);
+        wave_sync();
+    }
     // hit_test (core/world.py:73-99) for the envs that place or break -- 8 of the 18 walking actions.
     Hit h;
     h.hit = false; h.have_prev = false;
