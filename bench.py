@@ -185,7 +185,7 @@ def cgroup_cpu_quota():
     return None
 
 
-def cpu_baseline(seed):
+def cpu_baseline(seed, scale=1.0):
     """Oracle (plain-C port of the reference algorithm) on the host cores, bounded samples (about 25 s in all):
     the headline workload (rt20 targets, counter-RNG uniform actions, resets included) on every usable core and on
     one; BASELINE configs[3] (flying) likewise; BASELINE configs[0] (1 env, DUMMY_TASK-equivalent, size_reward=True,
@@ -206,6 +206,8 @@ def cpu_baseline(seed):
     def leg(mode, budget_s):
         kw = dict(size_reward=False) if mode == 'walking' else dict(size_reward=False, action_space='flying')
         n = int(min(16384, max(256, 1024 * cores)))   # (about 10 s of CPU work on the box's 16 granted cores)
+        if scale < 0.25:   # (tests: a sample of a second or two)
+            n = max(256, n // 8)
         tg = workloads.rt20(n, seed).numpy()
         b = O.OracleBatch(n, **kw)
         b.set_tasks(tg)
@@ -223,8 +225,8 @@ def cpu_baseline(seed):
         rate1, dt1, _ = timed(b1, fn1, 250, 1)
         return rate, dt, p, n, T, rate1, dt1, n1
 
-    rate, dt, p, n, T, rate1, dt1, n1 = leg('walking', 8.0)
-    frate, fdt, fp, fn_, fT, frate1, fdt1, fn1 = leg('flying', 6.0)
+    rate, dt, p, n, T, rate1, dt1, n1 = leg('walking', 8.0 * scale)
+    frate, fdt, fp, fn_, fT, frate1, fdt1, fn1 = leg('flying', 6.0 * scale)
     # BASELINE configs[0]: the loop of examples/run_env.py (1 env, DUMMY_TASK-equivalent, size_reward default True)
     dummy = np.zeros((1, 9, 11, 11), np.int8)
     dummy[0, 8, 10, 10] = 1
@@ -275,8 +277,9 @@ def load_profile(suffix, kind='', library_build_id=None, profiles_dir=None):
 
 
 def auto_lanes(n):
-    """The library's automatic group width (include/igw.h: IGW_AUTO_*_MAX)."""
-    return 32 if n <= 1024 else 16 if n <= 4096 else 8 if n <= 24576 else 4
+    """The library's automatic group width (include/igw.h: IGW_AUTO_*_MAX; one host-side copy: gridworld_amd/_lib.py)."""
+    from gridworld_amd import _lib
+    return _lib.auto_lanes(n)
 
 
 def dry_run(args):
@@ -585,7 +588,7 @@ class Runner:
 HBM_ACHIEVABLE_GBS = 6300.0   # what a streaming kernel reaches on this part (MI355X_MICROARCH.md)
 
 
-def roofline_of(r, m, lanes, has_start_frac=0.0, profiles_dir=None):
+def roofline_of(r, m, lanes, has_start_frac=0.0, profiles_dir=None, kind=None):
     """The roofline object of a measured workload.
 
     `achieved` / `frac` are PHYSICAL: the HBM bytes one launch of the dominant kernel moves -- FETCH_SIZE / WRITE_SIZE
@@ -617,7 +620,8 @@ def roofline_of(r, m, lanes, has_start_frac=0.0, profiles_dir=None):
     per_reset = 128 + 1104 + 192 + 1024 + 16 + has_start_frac * (1104 + 192)
     design = base + pc * per_cell + resets_per_step * per_reset
     lib_id = L.build_id()
-    kind = 'flying' if flying else ('cdm' if r.workload == 'cdm' else '')
+    if kind is None:
+        kind = 'flying' if flying else ('cdm' if r.workload == 'cdm' else '')
     traffic = load_profile('traffic.json', kind, lib_id, profiles_dir)
     issue = load_profile('issue.json', kind, lib_id, profiles_dir)
     hbm_bytes = None if traffic is None else traffic.get('hbm_bytes_per_launch')
@@ -674,9 +678,48 @@ def roofline_of(r, m, lanes, has_start_frac=0.0, profiles_dir=None):
                'peak': 1.0, 'unit': 'VALU issue cycles per SIMD cycle',
                'valu_issue_util_per_simd': None if not valu else valu * waves_per_simd * 4.0 / (kernel_s * GPU_CLOCK_GHZ * 1e9),
                'valu_insts_per_env_step': None if not valu else valu * lanes / 64.0}
-    roof['issue'] = iss
-    roof['issue_util'] = None if iss is None else iss['valu_issue_util_per_simd']
-    return roof, iss
+    util = None if iss is None else iss['valu_issue_util_per_simd']
+    mall = N * (192 + 64 + 64 + 16 + 64) <= 256e6   # the per-step records + bitmaps of the batch fit the 256 MB Infinity Cache
+    roof['note'] = ('FETCH_SIZE / WRITE_SIZE count requests that leave the XCD L2s for the fabric; Infinity-Cache (MALL) hits are '
+                    'included (MI355X_MICROARCH.md).  At %s envs the per-step working set (%.0f MB of bitmaps and records + the '
+                    'touched histogram rows) %s the 256 MB Infinity Cache, so this is %s.'
+                    % (f'{N:,}', N * (192 + 64 + 64 + 16 + 64) / 1e6, 'fits' if mall else 'exceeds',
+                       'fabric traffic served mostly by the Infinity Cache, not DRAM streaming: see config.large for the batch size '
+                       'at which 8 TB/s is the ceiling' if mall else 'DRAM traffic: the regime in which the 8 TB/s of HBM3E is the ceiling'))
+    if util is None:   # no SQ profile of this build: the HBM object stands alone (as in rounds 1-5)
+        roof['issue'] = iss
+        roof['issue_util'] = None
+        return roof, iss
+    # The top-level object names what bounds the kernel: VALU instruction issue.  `achieved` = the share
+    # of the launch in which a SIMD's vector ALU is issuing (VALU instructions per wavefront of the committed SQ profile x
+    # wavefronts per SIMD x 4 cycles, over THIS run's kernel time); `traffic` = the PMC bytes per launch as the contract asks;
+    # the HBM-side fraction stays beside it as `hbm`.
+    top = {'bound': 'issue', 'achieved': util, 'peak': 1.0, 'unit': 'VALU issue cycles per SIMD cycle', 'frac': util,
+           'traffic': roof['traffic'], 'kernel': roof['kernel'], 'kernel_avg_ms': kernel_ms,
+           'stale': bool(iss['stale']) or bool(stale),
+           'what': 'the step kernel is bound by vector-ALU instruction issue of the four wavefronts that share a SIMD and by the '
+                   'launch structure around it (launch ramp, input burst, the wait for the slowest wavefront), not by HBM: '
+                   'frac = VALU issue utilisation; hbm = the PMC traffic fraction (rounds 1-5 had this at the top level)',
+           'valu_insts_per_wave': iss['from_profile']['valu_insts_per_wave'], 'waves_per_simd': iss['waves_per_simd'],
+           'hbm': roof, 'issue': iss, 'issue_util': util, 'limiter': 'issue',
+           'measured_in_this_run': ['kernel_avg_ms', 'hbm.design_bytes_per_env_step (p_changed, resets counted on the device)'],
+           'from_profile': ['traffic', 'valu_insts_per_wave', 'hbm.traffic', 'issue.from_profile.*']}
+    return top, iss
+
+
+HBM_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'basis', 'stale', 'kernel', 'kernel_avg_ms',
+            'design_bytes_per_env_step', 'wasted_traffic', 'frac_of_achievable', 'frac_convention', 'profile', 'limiter', 'note')
+
+
+def slim_roofline(roof):
+    """The roofline object of a secondary workload: the top level (what bounds the kernel) and the HBM side without the
+    long explanatory fields."""
+    if 'hbm' not in roof:
+        return {k: roof[k] for k in HBM_KEYS if k in roof}
+    out = {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_avg_ms', 'stale',
+                                'valu_insts_per_wave', 'waves_per_simd', 'limiter')}
+    out['hbm'] = {k: roof['hbm'][k] for k in HBM_KEYS if k in roof['hbm']}
+    return out
 
 
 def facade_rate(seed, steps=3000):
@@ -879,9 +922,7 @@ def run(args):
                 'windows_ms_per_step': m2['windows_ms_per_step'], 'kernel_us': 1e3 * m2['kernel_ms'],
                 'p_changed': m2['p_changed'], 'p_cell_changed': m2['p_cell_changed'],
                 'resets_in_window': m2['resets_in_window'], 'timed_as': r2.timed_as,
-                'roofline': {k: roof2[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'basis', 'stale', 'kernel',
-                                                   'kernel_avg_ms', 'design_bytes_per_env_step', 'wasted_traffic', 'frac_of_achievable',
-                                                   'frac_convention', 'profile', 'limiter')},
+                'roofline': slim_roofline(roof2),
                 'valu_issue_util_per_simd': None if iss2 is None else iss2['valu_issue_util_per_simd']}
             del r2
             torch.cuda.empty_cache()
@@ -908,6 +949,41 @@ def run(args):
         del r3
         torch.cuda.empty_cache()
         facade = facade_rate(args.seed)
+
+    # config.sweep: the same workload and window at larger batches per GPU -- envs_per_gpu is a tunable of the API, and the
+    # launch structure (launch ramp, input burst, the wait for the slowest wavefront: about 30 % of a 65,536-env launch)
+    # amortises with it; the headline stays BASELINE's 65,536.  The largest size (>= 2,097,152 envs: 0.8 GB of bitmaps and
+    # records per step, beyond the 256 MB Infinity Cache) is also config.large, with its own PMC profile
+    # (profiles/r*_large_traffic.json): the one regime in which the HBM roofline is the roofline.
+    sweep = large = None
+    sizes = []
+    if world == 1 and not args.no_secondary and not flying and args.workload == 'rt20' and not args.debug_flags and args.sweep:
+        sizes = sorted({int(x) for x in args.sweep.split(',') if x.strip()} - {N})
+    if sizes:
+        sweep = {str(N): {'value': N * K / max_elapsed, 'ms_per_step': 1e3 * max_elapsed / K, 'kernel_us': 1e3 * m['kernel_ms'],
+                          'kernel_us_per_65536_env_steps': 1e3 * m['kernel_ms'] * 65536.0 / N, 'lanes_per_env': lanes, 'headline': True}}
+        for Ns in sizes:
+            try:
+                r4 = Runner(args, 'walking', 'rt20', device, rank, world, node_barrier, N=Ns)
+                m4 = r4.measure(3, 1)
+                lanes4 = r4.env.cfg.lanes_per_env or auto_lanes(Ns)
+                sweep[str(Ns)] = {'value': Ns * K / m4['elapsed'], 'ms_per_step': 1e3 * m4['elapsed'] / K, 'kernel_us': 1e3 * m4['kernel_ms'],
+                                  'kernel_us_per_65536_env_steps': 1e3 * m4['kernel_ms'] * 65536.0 / Ns, 'lanes_per_env': lanes4,
+                                  'windows_ms_per_step': m4['windows_ms_per_step'], 'p_changed': m4['p_changed']}
+                if Ns == sizes[-1] and Ns >= 2097152:
+                    roof4, iss4 = roofline_of(r4, m4, lanes4, kind='large')
+                    large = {'workload': 'configs[2] at %s envs on ONE GPU: walking Discrete(18), rt20 targets (one private task row per '
+                                         'env), uniform random actions, auto-reset at done; per step %.2f GB of bitmaps, records and '
+                                         'histogram rows -- beyond the 256 MB Infinity Cache' % (f'{Ns:,}', Ns * 614e-9),
+                             'envs': Ns, 'value': Ns * K / m4['elapsed'], 'unit': 'env-steps/s', 'ms_per_step': 1e3 * m4['elapsed'] / K,
+                             'kernel_us': 1e3 * m4['kernel_ms'], 'kernel_us_per_65536_env_steps': 1e3 * m4['kernel_ms'] * 65536.0 / Ns,
+                             'p_changed': m4['p_changed'], 'resets_in_window': m4['resets_in_window'], 'timed_as': r4.timed_as,
+                             'device_memory_gb': torch.cuda.max_memory_allocated(device) / 1e9,
+                             'roofline': slim_roofline(roof4)}
+                del r4
+            except Exception as e:  # noqa: BLE001 -- a size that does not fit (another process on the GPU) must not lose the headline
+                sweep[str(Ns)] = {'error': (str(e).splitlines() or [type(e).__name__])[0][:200]}
+            torch.cuda.empty_cache()
 
     if rank != 0:
         return None
@@ -985,12 +1061,22 @@ def run(args):
     out['config'].update(secondary)
     if small is not None:
         out['config']['small'] = small
+    if sweep is not None:
+        out['config']['sweep'] = sweep
+        out['config']['sweep_note'] = ('envs_per_gpu is a tunable (VecGridWorld(num_envs)): same workload, same window, 3 windows each; '
+                                       'kernel_us_per_65536_env_steps = the launch time scaled to the headline batch')
+    if large is not None:
+        out['config']['large'] = large
     if facade is not None:
         out['config']['facade_1env'] = facade
     if iss is not None:
         out['issue'] = iss
-    if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args.seed)
+    if not args.no_cpu_baseline:
+        # on rank 0 at every N (north star: "next to the reference CPU path timed on the node's own host cores ... in the
+        # same run").  The windows are over; with N > 1 the other ranks have returned and wait in the closing gloo barrier
+        # (blocked in a socket read, not spinning), so rank 0 has the node's granted cores for the sample.
+        out['cpu_baseline'] = cpu_baseline(args.seed, scale=args.cpu_sample_scale)
+        out['cpu_baseline']['timed_on'] = 'rank 0, after the timed windows' + ('' if world == 1 else f' (the other {world - 1} ranks idle in the closing barrier)')
     print(json.dumps(out), flush=True)
 
 

@@ -27,6 +27,13 @@ TASK_INDEX_BYTES = 9 * LEVEL_INDEX_BYTES
 WALKING_DISCRETE, FLYING, WALKING_DICT = 0, 1, 2
 RESET_KEEP_SIZE = 1
 CAMERA_MAX = 1e6   # IGW_CAMERA_MAX
+AUTO_32_MAX, AUTO_16_MAX, AUTO_8_MAX = 1024, 4096, 24576   # IGW_AUTO_*_MAX (checked against the header by tests/test_abi.py)
+
+
+def auto_lanes(num_envs):
+    """The group width igw_create chooses for lanes_per_env = 0 (include/igw.h: IGW_AUTO_*_MAX) -- the ONE host-side
+    copy of that rule (VecGridWorld.split, bench.py)."""
+    return 32 if num_envs <= AUTO_32_MAX else 16 if num_envs <= AUTO_16_MAX else 8 if num_envs <= AUTO_8_MAX else 4
 
 # every symbol include/igw.h declares (checked by tests/test_abi.py)
 EXPORTS = ['igw_version', 'igw_build_id', 'igw_last_error', 'igw_device_count', 'igw_create', 'igw_destroy', 'igw_debug_set_stamps',

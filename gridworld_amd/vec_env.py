@@ -628,8 +628,7 @@ class SubBatch:
         cfg.num_envs = n
         cfg.env_index_base = parent.env_index_base + lo
         if cfg.lanes_per_env == 0:   # the group width the library chose for the WHOLE batch (include/igw.h: IGW_AUTO_*)
-            N = parent.num_envs
-            cfg.lanes_per_env = 32 if N <= 1024 else 16 if N <= 4096 else 8 if N <= 24576 else 4
+            cfg.lanes_per_env = L.auto_lanes(parent.num_envs)
         self.cfg = cfg
         self.ctx = C.c_void_p()
         L.check(self.lib.igw_create(C.byref(cfg), C.byref(self.ctx)), 'igw_create')

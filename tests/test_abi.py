@@ -38,12 +38,15 @@ def test_layout_constants_match_header():
                       ('IGW_STAT_STRIPES', _lib.STAT_STRIPES), ('IGW_OCC_WORDS', _lib.OCC_WORDS),
                       ('IGW_TRAJ_BYTES', _lib.TRAJ_BYTES), ('IGW_VERSION', _lib.VERSION),
                       ('IGW_STAT_BAD_POSE', _lib.STAT_BAD_POSE), ('IGW_STAT_BAD_ACTION', _lib.STAT_BAD_ACTION),
-                      ('IGW_STAT_BAD_TASK', _lib.STAT_BAD_TASK), ('IGW_LEVEL_INDEX_BYTES', _lib.LEVEL_INDEX_BYTES)):
+                      ('IGW_STAT_BAD_TASK', _lib.STAT_BAD_TASK), ('IGW_LEVEL_INDEX_BYTES', _lib.LEVEL_INDEX_BYTES),
+                      ('IGW_AUTO_32_MAX', _lib.AUTO_32_MAX), ('IGW_AUTO_16_MAX', _lib.AUTO_16_MAX), ('IGW_AUTO_8_MAX', _lib.AUTO_8_MAX),
+                      ('IGW_STAT_STEPS', _lib.STAT_STEPS)):
         m = re.search(r'#define\s+%s\s+(\d+)' % name, src)
         assert m and int(m.group(1)) == val, name
     assert ctypes.sizeof(_lib.Config) == 64
     assert ctypes.sizeof(_lib.Buffers) == 12 * ctypes.sizeof(ctypes.c_void_p)
     assert _lib.TASK_INDEX_BYTES == 9 * _lib.LEVEL_INDEX_BYTES
+    assert [_lib.auto_lanes(n) for n in (1, 1024, 1025, 4096, 4097, 24576, 24577, 65536)] == [32, 32, 16, 16, 8, 8, 4, 4]
 
 
 def test_fails_loudly_without_device():

@@ -51,7 +51,8 @@ def test_two_ranks_through_torchrun_on_one_shared_gpu():
     `python -m torch.distributed.run` (child processes, started before anything touches the GPU) and IGW_SHARE_GPU=1
     puts both on cuda:0.  Checked: rendezvous, the shared-memory barrier of the timing bracket, the per-window max over
     ranks, the gather of every rank's DEVICE-SIDE step counter (IGW_STAT_STEPS delta of the window) with `value`
-    computed from their sum, a clean exit of both ranks.  RCCL refuses two ranks on one device, so the gather takes the
+    computed from their sum, `cpu_baseline` (rank 0, a one-second sample here) and `roofline` on the N > 1 line,
+    a clean exit of both ranks.  RCCL refuses two ranks on one device, so the gather takes the
     agreed gloo fallback here (on a real node it is RCCL over xGMI; the one-rank RCCL gather is the test above).
     NO scaling number can be read from this: both ranks share one GPU."""
     import json
@@ -60,7 +61,7 @@ def test_two_ranks_through_torchrun_on_one_shared_gpu():
         env.pop(k, None)
     n, k = 8192, 20
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', str(k), '--warmup', '5', '--envs-per-gpu', str(n),
-           '--windows', '3', '--rehearsals', '1', '--no-cpu-baseline', '--no-secondary', '--no-api', '--no-fused', '--no-async']
+           '--windows', '3', '--rehearsals', '1', '--cpu-sample-scale', '0.05', '--no-secondary', '--no-api', '--no-fused', '--no-async']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
@@ -70,3 +71,10 @@ def test_two_ranks_through_torchrun_on_one_shared_gpu():
     assert abs(line['value'] - 2 * n * k / (line['ms_per_step'] * 1e-3 * k)) < 1e-6 * line['value']
     assert 'rccl' in cfg['step_count_gather'] or 'gloo' in cfg['step_count_gather']
     assert len(cfg['kernel_us_per_rank']) == 2 and line['scaling'] == 'weak'
+    # the N > 1 line is complete (north star: the CPU path timed in the same run, the roofline of the kernel):
+    cb = line['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and 'rank 0' in cb['timed_on'] and 'sample' in cb
+    rf = line['roofline']
+    assert rf['bound'] in ('issue', 'hbm') and rf['kernel_avg_ms'] > 0 and len(cfg['kernel_us_per_rank']) == 2
+    hbm = rf.get('hbm', rf)
+    assert hbm['bound'] == 'hbm' and hbm['peak'] == 8000.0 and hbm['achieved'] > 0

@@ -178,6 +178,28 @@ def test_flying_divergence_from_glibc_reference_at_scale(capsys):
     assert res['max_abs_float64_deviation_of_clean_envs'] < 1e-9
 
 
+def test_walking_dict_divergence_from_glibc_reference_at_scale(capsys):
+    """The same residual for the OTHER action space that sends arbitrary float angles through the general trig: walking
+    with discretize=False (parse_walking_action, core/world.py:396-414: continuous camera deltas, so yaw and pitch leave
+    the 5-degree lattice; button combinations whose diagonal strafes go through atan2, :163-201).  All 65,536 envs x
+    full 250-step episodes against the oracle computing with GLIBC trig, every env, every step -- nothing of the
+    product's trig on the checker's side.  The >= 1e8-step run is profiles/r06_adict_divergence.json."""
+    import json
+    import os
+    import afly_divergence as AD
+    res, _ = AD.one_pass(65536, 250, seed=505, space='walking_dict')
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/adict_divergence_test.json', 'w') as f:
+        json.dump(res, f, indent=1)
+    with capsys.disabled():
+        print('\nwalking-Dict divergence vs glibc reference:', json.dumps(res))
+    assert res['action_space'] == 'walking_dict' and res['env_steps'] == 65536 * 250
+    assert res['all_done'] and res['min_inventory'] >= 0
+    assert res['envs_with_integer_divergence'] <= 2
+    assert res['envs_with_float32_obs_divergence'] <= 8
+    assert res['max_abs_float64_deviation_of_clean_envs'] < 1e-9
+
+
 @pytest.mark.parametrize('autoreset', [True, False])
 @pytest.mark.parametrize('gs', [0, 4, 1])
 def test_flying_rollout_over_recorded_actions_equals_stepping(gs, autoreset):

@@ -244,3 +244,91 @@ def test_cdm_workload_full_size_properties():
     assert np.array_equal(env.internals()[idx].view(np.uint64), ob.internals().view(np.uint64))
     assert np.array_equal(env.reward.cpu().numpy()[idx], ob.reward)
     assert np.array_equal(env.inventory.cpu().numpy()[idx], ob.inventory)
+
+
+def _rng_task_host(seed, env, episode, n):
+    """Host restatement (numpy uint64) of the device's task sampler -- csrc/igw_device.h rng_task(): the row an env
+    draws at the reset that ends episode `episode` -- so the oracle replay below does not ask the device which task
+    it chose (CustomTasks.reset, gridworld/tasks/task_set.py:53-56: uniform over the table)."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def splitmix(z):
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over='ignore'):
+        env = np.asarray(env, np.uint64)
+        episode = np.asarray(episode, np.uint64)
+        h = splitmix(np.uint64(seed) ^ splitmix(env * np.uint64(0x9E3779B1) + episode * np.uint64(0x100000001B3) + np.uint64(0x7461736B)))
+        return (((h >> np.uint64(32)) * np.uint64(n)) >> np.uint64(32)).astype(np.int64)
+
+
+def test_extra_kernel_variant_whole_batch_equals_oracle_at_full_size():
+    """The EXTRA instantiation of the step kernel (step_kernel<4, 0, true>: episode log + device-side samplers compiled
+    in) at BASELINE's full batch: 65,536 envs, the on-device task sampler drawing every episode's task from a 4,096-row
+    table (a third of the rows with a starting grid), the episode log on for the first 64 envs, auto-reset inside the
+    kernel, 260 steps with max_steps = 100 -- and EVERY env replayed through the CPU oracle step by step: done and
+    reward of the whole batch every step, the task rows the device drew against a host restatement of its sampler, the
+    decoded log of every finished episode of the logged envs against the oracle's own record (gridworld/wrappers.py:89-121),
+    and at the end grid, float64 internals, inventory and observations of all 65,536 envs bit for bit."""
+    from fuzz_parity import LogChecker, compare
+    from gridworld_amd import VecGridWorld, workloads
+    from oracle import oracle as O
+    T, ntasks, samp_seed, n_logged = 260, 4096, 424242, 64
+    kw = dict(size_reward=False, max_steps=100)
+    tg = workloads.rt20(ntasks, seed=61).numpy()
+    st = np.zeros_like(tg)
+    st[::3, 0, 5, 5] = 2                      # a third of the rows start with a block in place
+    st[1::3, 1, 3, 7] = 5                     # ... another third with one that is (usually) not part of the target
+    env = VecGridWorld(N, num_tasks=ntasks, autoreset=True, **kw)
+    env.set_tasks(tg, st, env_task=np.zeros(N, np.int32))
+    env.set_task_sampling(True, seed=samp_seed)
+    ob = O.OracleBatch(N, **kw)
+    checker = LogChecker(env, ob, n_logged, kw['max_steps'], 'EXTRA full size')
+    env.reset()
+    torch.cuda.synchronize()
+    assert env.cfg.lanes_per_env in (0, 4)
+    episode = np.zeros(N, np.int64)           # episodes started so far = the sampler's key of the NEXT draw
+    row = _rng_task_host(samp_seed, np.arange(N), episode, ntasks)
+    episode += 1
+    assert np.array_equal(env.env_task.cpu().numpy(), row)
+    for e in range(N):
+        ob.envs[e].set_task(tg[row[e]], st[row[e]])
+    ob.reset()
+    checker.begin(None)
+    acts = env.fill_actions(T, seed=8086)
+    acts_h = acts.cpu().numpy()
+    n_resets = 0
+    try:
+        for t in range(T):
+            env.step(acts[t])
+            ob.step_walking(acts_h[t], autoreset=False, nthreads=16)
+            checker.step()
+            torch.cuda.synchronize()
+            done = ob.done.astype(bool)
+            assert np.array_equal(env.done.cpu().numpy().astype(bool), done), t
+            assert np.array_equal(env.reward.cpu().numpy().view(np.uint32), ob.reward.view(np.uint32)), t
+            if done.any():
+                idx = np.nonzero(done)[0]
+                row[idx] = _rng_task_host(samp_seed, idx, episode[idx], ntasks)
+                episode[idx] += 1
+                n_resets += len(idx)
+                rew, dn = ob.reward.copy(), ob.done.copy()
+                for e in idx:
+                    ob.envs[e].set_task(tg[row[e]], st[row[e]])
+                ob.reset(done)
+                ob.reward[:], ob.done[:] = rew, dn      # (reward / done stay the step's, as on the device)
+                checker.begin(done)
+            checker.check()
+            if t % 20 == 19 or t == T - 1:
+                assert np.array_equal(env.env_task.cpu().numpy(), row), t
+                compare(env, ob, f'EXTRA full size, step {t}')
+        assert np.array_equal(env.internals().view(np.uint64), ob.internals().view(np.uint64))
+        s = env.stats()
+        assert s['resets'] == n_resets and n_resets >= 2 * N and s['steps'] == N * T
+        assert checker.checked >= 2 * n_logged
+        picks = np.bincount(row, minlength=ntasks)
+        assert picks.max() <= 60 and (picks > 0).mean() > 0.99      # 16 draws per row on average: roughly uniform
+    finally:
+        env.disable_trajectory_log()
