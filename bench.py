@@ -546,8 +546,16 @@ class Runner:
             self.busy(0.3, 0)
         rehearsal_ms = [round(1e3 * self.window()[0] / K, 5) for _ in range(rehearsals)]
         walls, kernels, ps, resets, cells, counted, timelines = [], [], [], [], [], [], []
+        import gc
         for _ in range(max(1, windows)):
-            el, st0_dev, kms, host_tl = self.window()
+            # (a cyclic-GC pass of the interpreter inside a 250-us window is a 20-50 % outlier: collect between windows,
+            # not in them)
+            gc.collect()
+            gc.disable()
+            try:
+                el, st0_dev, kms, host_tl = self.window()
+            finally:
+                gc.enable()
             timelines.append(host_tl)
             s0, s1 = st0_dev.cpu(), env.stats_tensor().cpu()
             walls.append(el)

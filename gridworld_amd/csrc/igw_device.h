@@ -42,6 +42,14 @@ __device__ inline void prio_at(bool boost = false) {
         else __builtin_amdgcn_s_setprio(level);
     }
 }
+// Round-6 variants of the step path (same-box A/B: profiles/r06_ab_variants.txt; together -0.5 % walking, -0.4 % CDM):
+// the ray march's sample exchange as a 4 x 4 byte transpose of the quad; |p - np| as an operand modifier in the sub-steps
+#ifndef IGW_MARCH_TRANSPOSE
+#define IGW_MARCH_TRANSPOSE 1
+#endif
+#ifndef IGW_ABS_SGN
+#define IGW_ABS_SGN 1
+#endif
 #ifndef IGW_BLOCK
 #define IGW_BLOCK 256
 #endif
@@ -469,7 +477,7 @@ __host__ __device__ constexpr uint32_t occ_const_word(int w) {
 // ---------------------------------------------------------------- trig front-end
 
 struct TrigCtx {
-    const double* lut;  // LDS copy of IGW_TRIG_LUT: {cos, sin} of radians(5k), k = IGW_LUT_K0..
+    const double* lut;  // IGW_TRIG_LUT in constant memory: {cos, sin} of radians(5k), k = IGW_LUT_K0..
 };
 
 // cos / sin of math.radians(deg).  Multiples of 5 degrees inside the table (all that discrete
@@ -654,7 +662,11 @@ __device__ inline double substeps_owned(const Grp<GS>& G, Env& e, const uint32_t
         const int za = clampi(nz + uz * i1, -6, 6) + 6 + OCC_IDX0;
         const int ya0 = (clampi(ny + uy * i1, -4, 8) + 4) * OCC_LAYER, ya1 = (clampi(ny + uy * i1 - 1, -4, 8) + 4) * OCC_LAYER;
         const bool b1 = (int)occ_test(occ_s, ya0 + xa + za) | (int)occ_test(occ_s, ya1 + xa + za);
+#if IGW_ABS_SGN
+        const double d = __builtin_fabs(sgn);   // == sgn * f1 exactly (f1 = +-1 with the sign of sgn): an operand modifier, no instruction
+#else
         const double d = sgn * f1;
+#endif
         const bool h1 = !(d < PAD) && b1;
         const double r = h1 ? c - (d - PAD) * f1 : c;
         pa = moves ? r : pa;
@@ -735,8 +747,14 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
         const double sc = div5(a == 0 ? vx : a == 1 ? vy : vz);  // dx / m with m = 5
         const double magic = RINT_MAGIC + (a == 1 ? 4.0 : 6.0);
         // byte selectors (v_perm_b32: 0-3 = bytes of the second source, 4-7 = bytes of the first, 0x0c = zero)
+#if IGW_MARCH_TRANSPOSE
+        // the 4 x 4 byte transpose of a quad in two exchange stages (lane ^ 1, lane ^ 2): one v_perm_b32 per stage
+        const unsigned sel_1 = (G.gl & 1) ? 0x03070105u : 0x06020400u;   // odd: (partner1, own1, partner3, own3); even: (own0, partner0, own2, partner2)
+        const unsigned sel_2 = (G.gl & 2) ? 0x03020706u : 0x05040100u;   // lanes 2, 3: (partner2, partner3, own2, own3); lanes 0, 1: (own0, own1, partner0, partner1)
+#else
         const unsigned sel_xy = 0x0c0c0000u | (unsigned)G.gl | ((4u + (unsigned)G.gl) << 8);
         const unsigned sel_z = 0x0c000100u | ((4u + (unsigned)G.gl) << 16);
+#endif
         uint32_t* const mine = scratch + G.lane;
         int kidx[ROUNDS];
         uint32_t word[ROUNDS];
@@ -753,10 +771,18 @@ __device__ inline Hit hit_test(const Grp<GS>& G, const uint32_t* occ_s, double x
                 sdwa_min_into_byte(w, (uint32_t)__double2loint(c + magic), twelve, j);
                 if (r * 4 + j + 1 < SAMPLES) c = c + sc;
             }
+#if IGW_MARCH_TRANSPOSE
+            // Lane c of the quad holds the four samples of coordinate c (x, y, z, z) as the bytes of w; lane j needs byte j of
+            // every lane: a 4 x 4 byte transpose, two DPP exchanges + two v_perm_b32 (three broadcasts + two perms before).
+            // Byte 3 of the key is lane 3's copy of z: key_idx() weighs it with zero, key_unpack() masks it off.
+            const unsigned u1 = __builtin_amdgcn_perm((unsigned)dpp_quad<QUAD_XOR1>((int)w), w, sel_1);
+            const int key = (int)__builtin_amdgcn_perm((unsigned)dpp_quad<QUAD_XOR2>((int)u1), u1, sel_2);
+#else
             const unsigned wx = (unsigned)dpp_quad<QUAD_BCAST0>((int)w), wy = (unsigned)dpp_quad<QUAD_BCAST1>((int)w),
                            wz = (unsigned)dpp_quad<QUAD_BCAST2>((int)w);
             // byte gl of wx, wy, wz -> bytes 0, 1, 2 of the key
             const int key = (int)__builtin_amdgcn_perm(wz, __builtin_amdgcn_perm(wy, wx, sel_xy), sel_z);
+#endif
             kidx[r] = key_idx(key);
             word[r] = occ_s[kidx[r] >> 5];  // all probes are issued before the first is consumed
             mine[r * WAVE] = (uint32_t)key;

@@ -70,9 +70,10 @@ __device__ inline void stamp_features(const KParams&, unsigned long long) {}
 // IGW_STEPS_MODE: how a step launch adds its env-steps to IGW_STAT_STEPS (2: once per launch; 1: once per block --
 // round 5; 0: not at all -- round 4; the other two exist for the same-box A/B of tools/ab_variants.sh)
 // IGW_SPLIT_BURST: the step kernel waits for its small input loads first and for the occupancy pieces behind the
-// action parse / trig (see step_kernel); 0 = one wait for the whole burst (rounds 3-5)
+// action parse / trig (see step_kernel); 0 = one wait for the whole burst (rounds 3-5).  Same-box A/B
+// (profiles/r06_ab_variants.txt): -0.4 % walking, -1.1 % flying (its trig runs while the occupancy rows arrive).
 #ifndef IGW_SPLIT_BURST
-#define IGW_SPLIT_BURST 0
+#define IGW_SPLIT_BURST 1
 #endif
 #ifndef IGW_STEPS_MODE
 #define IGW_STEPS_MODE 2
@@ -680,12 +681,15 @@ struct TailParams {
     unsigned long long* stats;
     uint32_t* occ;
 };
-__device__ inline TailParams tail_params(const KParams& p) {
-    TailParams t = {p.max_steps, p.size_reward, p.autoreset, p.right_scale, p.wrong_scale, p.out, p.agent, p.aux, p.stats, p.occ};
+__device__ inline void tail_params_pin(TailParams& t) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(t.max_steps), "+s"(t.size_reward), "+s"(t.autoreset), "+s"(t.right_scale), "+s"(t.wrong_scale),
                  "+s"(t.out), "+s"(t.agent), "+s"(t.aux), "+s"(t.stats), "+s"(t.occ));
 #endif
+}
+__device__ inline TailParams tail_params(const KParams& p) {
+    TailParams t = {p.max_steps, p.size_reward, p.autoreset, p.right_scale, p.wrong_scale, p.out, p.agent, p.aux, p.stats, p.occ};
+    tail_params_pin(t);
     return t;
 }
 
@@ -898,9 +902,36 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 #define IGW_LDS(p) ((lds_u32*)(uintptr_t)(uint32_t) reinterpret_cast<uintptr_t>(p))  /* low half of a flat LDS address = LDS offset */
 __device__ inline void glds16(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 16, 0, 0); }
 __device__ inline void glds16_sc1(const void* src, uint32_t* dst) { __builtin_amdgcn_global_load_lds(src, IGW_LDS(dst), 16, 0, 16); }
+// The same LDS-DMA as inline assembly -- UNTRACKED by the compiler's s_waitcnt insertion.  A tracked LDS-DMA makes the
+// compiler put s_waitcnt vmcnt(0) in front of every later LDS access that might alias its destination, until it sees a
+// wait of its own: the explicit asm waits below do not count, so the histogram update opened with FOUR vmcnt(0) -- each of
+// which also waits for the acknowledgement of the agent-record store issued just before (the counter is in order over
+// loads and stores), a store round trip at the start of the latency-bound phase of two wavefronts in three.  Untracked,
+// the only waits are the explicit ones (every consumer of DMA'd rows has one: step_kernel in front of the agent store,
+// resolve_changes for the later chunks).  The fused rollout keeps the builtin.  An untracked load can only make the compiler's
+// own waits stricter than necessary (it counts fewer loads in flight than there are), never weaker.
+// ubase: wave-uniform global address; voff: this lane's byte offset; dst: wave-uniform LDS destination (the hardware adds
+// 16 x lane and the instruction offset to BOTH addresses).  M0 (the LDS base) is saved and restored.
+__device__ inline void glds16u(const void* ubase, uint32_t voff, uint32_t* dst) {
+    // (low half of a flat LDS address = LDS offset; readfirstlane: the operands are wave-uniform, the compiler is told so
+    // -- on values that already are scalar it folds away)
+    const uint32_t lds_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t) reinterpret_cast<uintptr_t>(dst));
+    const uint64_t ub = (uint64_t) reinterpret_cast<uintptr_t>(ubase);
+    ubase = reinterpret_cast<const void*>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ub >> 32)) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub)));
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_keep) : "s"(lds_at), "v"(voff), "s"(ubase) : "memory");
+}
 #else
 __device__ inline void glds16(const void*, uint32_t*) {}
 __device__ inline void glds16_sc1(const void*, uint32_t*) {}
+__device__ inline void glds16u(const void*, uint32_t, uint32_t*) {}
+#endif
+// IGW_UNTRACKED_DMA: 1 = the step kernel's LDS-DMA through glds16u (see there); 0 = the compiler's builtin (rounds 3-5).
+// Same-box A/B (profiles/r06_ab_variants.txt): -1.7 % walking, -0.6 % CDM, -2.6 % flying.
+#ifndef IGW_UNTRACKED_DMA
+#define IGW_UNTRACKED_DMA 1
 #endif
 
 // The LDS-DMA loads of one changed env into scratch slot k (whole wave): its histogram row and the colour-index
@@ -909,6 +940,15 @@ __device__ inline void glds16_sc1(const void*, uint32_t*) {}
 template <bool L2>
 __device__ inline void dma_change_rows(const KParams& p, uint32_t* hist_dst, uint32_t* aux_dst, int env, int task, int level) {
     const int lane = __lane_id();
+#if IGW_UNTRACKED_DMA
+    if constexpr (!L2) {   // (the step kernel; the fused rollout keeps the builtin: its register budget has no slack, and every
+                           // step of it ends with a wait for everything anyway)
+        glds16u(p.hist + (size_t)env * HIST_ROW, 16u * (uint32_t)lane, hist_dst);
+        if (lane < LVL_BYTES / 16) glds16u(p.task_index + (size_t)task * IGW_TASK_INDEX_BYTES + level * LVL_BYTES, 16u * (uint32_t)lane, aux_dst);
+        return;
+    }
+#endif
+    {
     const char* hrow = reinterpret_cast<const char*>(p.hist + (size_t)env * HIST_ROW) + 16 * lane;
     if (L2) glds16_sc1(hrow, hist_dst);  // cache policy sc1
     else glds16(hrow, hist_dst);
@@ -916,6 +956,7 @@ __device__ inline void dma_change_rows(const KParams& p, uint32_t* hist_dst, uin
     if (lane < LVL_BYTES / 16) {
         if (L2) glds16_sc1(blk, aux_dst);
         else glds16(blk, aux_dst);
+    }
     }
 }
 template <int R, bool L2>
@@ -1533,9 +1574,15 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
         if (pm != 0 && __builtin_popcountll(chg_mask) < R) {
             staged_leader = __builtin_ctzll(pm);
             const int t_task = __builtin_amdgcn_readlane(task, staged_leader);
+#if IGW_UNTRACKED_DMA
+            const int8_t* row0 = p.task_start + (size_t)t_task * STRIDE;
+            glds16u(row0, 16u * (uint32_t)G.lane, sh.ws[wave].hist[R - 1]);
+            if (G.lane < CHUNKS - WAVE) glds16u(row0 + 16 * WAVE, 16u * (uint32_t)G.lane, sh.ws[wave].aux[R - 1]);
+#else
             const char* row = reinterpret_cast<const char*>(p.task_start + (size_t)t_task * STRIDE) + 16 * G.lane;
             glds16(row, sh.ws[wave].hist[R - 1]);
             if (G.lane < CHUNKS - WAVE) glds16(row + 16 * WAVE, sh.ws[wave].aux[R - 1]);
+#endif
             if (G.lane < OCC_WORDS) staged_occ = gload(p.task_start_occ + (size_t)t_task * OCC_WORDS + G.lane);
         }
     }

@@ -428,22 +428,27 @@ def make_vec(num_envs, device='cuda:0', **kwargs):
 
 def register(gym_module=None):
     """Registers 'IGLUGridworld-v0' and 'IGLUGridworldVector-v0' (gridworld/env.py:352-362) with `gym_module` --
-    anything with the classic `envs.register(id=, entry_point=, kwargs=)` -- or, by default, with whichever of
-    gymnasium / gym is importable.  Returns the names of the modules registered with.  An import error of an
-    absent package is the only thing ignored: a registry that rejects the ids raises."""
+    anything with the classic `envs.register(id=, entry_point=, kwargs=)` -- or, by default, with classic `gym` when it
+    is importable (what the reference registers with: its envs speak the old API -- `reset() -> obs`,
+    `step() -> (obs, reward, done, info)`).  `gymnasium` is NOT registered with automatically: its `make` wraps every env
+    in a passive checker and an order enforcer that expect the 5-tuple / `reset(seed=)` API; pass the module explicitly
+    (`register(gymnasium)`) to register the ids there with both wrappers switched off.  Returns the names of the
+    modules registered with.  An absent `gym` is the only thing ignored: a registry that rejects the ids raises."""
     mods = []
     if gym_module is not None:
         mods.append(gym_module)
     else:
         import importlib
-        for name in ('gymnasium', 'gym'):
-            try:
-                mods.append(importlib.import_module(name))
-            except ImportError:
-                pass
+        try:
+            mods.append(importlib.import_module('gym'))
+        except ImportError:
+            pass
     for mod in mods:
+        extra = {}
+        if getattr(mod, '__name__', '').split('.')[0] == 'gymnasium':
+            extra = dict(disable_env_checker=True, order_enforce=False)
         for env_id, kw in _REGISTRY.items():
-            mod.envs.register(id=env_id, entry_point='gridworld_amd.env:create_env', kwargs=dict(kw))
+            mod.envs.register(id=env_id, entry_point='gridworld_amd.env:create_env', kwargs=dict(kw), **extra)
     return [m.__name__ for m in mods]
 
 

@@ -299,8 +299,9 @@ def run_scenario(seed, backend, max_T=None):
                 check('reset.grid', np.array_equal(obs['grid'], o['grid']), t, 'grid')
                 check('reset.agentPos', np.array_equal(_b32(obs['agentPos']), _b32(o['agentPos'])), t, 'agentPos')
                 check('reset.compass', np.array_equal(_b32(obs['compass']), _b32(o['compass'])), t, 'compass')
-                check('reset.internal', np.array_equal(_b64(B.internals(env)), _b64(orc.internal())), t,
-                      [B.internals(env), orc.internal().tolist()])
+                if getattr(B, 'strict_float64', True):   # (agent.dy, time_int_steps survive a reset: SURVEY F7)
+                    check('reset.internal', np.array_equal(_b64(B.internals(env)), _b64(orc.internal())), t,
+                          [B.internals(env), orc.internal().tolist()])
                 st = orc.task_state()
                 check('reset.env_max_int', int(env.unwrapped.max_int) == st['env_max_int'], t,
                       [int(env.unwrapped.max_int), st['env_max_int']])
@@ -327,7 +328,14 @@ def run_scenario(seed, backend, max_T=None):
                     check('compass', np.array_equal(_b32(obs['compass']), _b32(o['compass'])), t,
                           [obs['compass'].tolist(), o['compass'].tolist()])
                     ri, oi = B.internals(env), orc.internal()
-                    check('internal', np.array_equal(_b64(ri), _b64(oi)), t, [ri, oi.tolist()])
+                    if getattr(B, 'strict_float64', True):
+                        check('internal', np.array_equal(_b64(ri), _b64(oi)), t, [ri, oi.tolist()])
+                    else:   # the A-fly contract (glibc on the checker's side): float64 internals may part in the last bits
+                        dev = float(np.abs(np.asarray(ri, np.float64) - np.asarray(oi, np.float64)).max())
+                        check('internal (|difference| < 1e-9)', dev < 1e-9, t, [ri, oi.tolist()])
+                        if not np.array_equal(_b64(ri), _b64(oi)):
+                            info['float64_diff_steps'] = info.get('float64_diff_steps', 0) + 1
+                            info['float64_max_dev'] = max(info.get('float64_max_dev', 0.0), dev)
                     st = orc.task_state()
                     smi, sps = B.syn(env)
                     check('syn_max_int', int(smi) == st['syn_max_int'], t, [int(smi), st['syn_max_int']])
@@ -362,7 +370,12 @@ def summarize(results, wall):
             d['steps'] += r['steps']
             d['mismatches'] += r['mismatch'] is not None
     bad = [r for r in results if r['mismatch'] is not None]
-    return dict(scenarios=len(results), env_steps=int(sum(r['steps'] for r in results)),
+    extra = {}
+    if any('float64_diff_steps' in r for r in results):
+        extra = dict(scenarios_with_a_float64_difference=sum(1 for r in results if r.get('float64_diff_steps')),
+                     steps_with_a_float64_difference=int(sum(r.get('float64_diff_steps', 0) for r in results)),
+                     max_abs_float64_deviation=max(r.get('float64_max_dev', 0.0) for r in results))
+    return dict(**extra, scenarios=len(results), env_steps=int(sum(r['steps'] for r in results)),
                 reference_env_steps=int(sum(r['steps'] for r in results)),
                 resets=int(sum(r['resets'] for r in results)), mismatches=len(bad), by=by,
                 first_mismatches=bad[:10], wall_s=round(wall, 1),
@@ -404,6 +417,18 @@ class ProductBackend:
         return env.unwrapped._counters
 
 
+class ProductBackendGlibc(ProductBackend):
+    """The same facade against the oracle computing with GLIBC sin / cos / atan2 (what the Python reference calls):
+    nothing of the product's trig on the checker's side.  The A-fly contract applies (tests/test_gpu_flying.py): every
+    integer output and every float32 observation bit-exact on every step; the float64 internals may part in the last
+    bits where glibc misrounds (counted and bounded, not asserted equal)."""
+    name = 'product-vs-glibc-oracle'
+    strict_float64 = False
+
+    def oracle_device_trig(self, crlibm):
+        return False
+
+
 def run(seeds, backend, max_T=None):
     t0 = time.time()
     results = [run_scenario_safe(int(s), backend, max_T) for s in seeds]
@@ -417,8 +442,9 @@ if __name__ == '__main__':   # product side on the GPU box: python tests/scenari
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 160
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
-    s = run(range(seed0, seed0 + n), ProductBackend())
-    s.update(seed0=seed0, backend='product: gridworld_amd.make(...) on the GPU vs oracle.OracleEnv (device-trig mode)',
+    glibc = len(sys.argv) > 4 and sys.argv[4] == 'glibc'     # 4th argument: the oracle computes with GLIBC trig (A-fly contract)
+    s = run(range(seed0, seed0 + n), ProductBackendGlibc() if glibc else ProductBackend())
+    s.update(seed0=seed0, backend='product: gridworld_amd.make(...) on the GPU vs oracle.OracleEnv (%s)' % ('glibc trig; integers + float32 bit-exact, float64 within last bits' if glibc else 'device-trig mode'),
              command=' '.join(sys.argv))
     s.pop('reference_env_steps', None)
     if len(sys.argv) > 3:

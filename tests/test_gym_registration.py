@@ -39,6 +39,12 @@ def test_register_puts_both_ids_into_the_registry(shim_gym):
     assert 'gym' in E.register()
     assert 'IGLUGridworldVector-v0' in shim_gym.envs.registry
 
+    import types
+    seen = []          # a module called gymnasium gets the ids with its checker / order-enforcer wrappers switched off
+    gymnasium = types.SimpleNamespace(__name__='gymnasium', envs=types.SimpleNamespace(register=lambda **kw: seen.append(kw)))
+    assert E.register(gymnasium) == ['gymnasium'] and len(seen) == 2
+    assert all(k['disable_env_checker'] is True and k['order_enforce'] is False for k in seen)
+
     class Refusing:
         __name__ = 'refusing'
 
