@@ -807,7 +807,7 @@ def run(args):
     m = r.measure(args.windows, args.rehearsals)
     max_elapsed = m['elapsed']
     # The one RCCL collective of the run (north star): every rank's DEVICE-SIDE step count of the median window --
-    # the delta of IGW_STAT_STEPS, which the step kernels add to once per block -- gathered over RCCL / xGMI; `value`
+    # the delta of IGW_STAT_STEPS, which every step launch adds its env count to (one atomic per launch) -- gathered over RCCL / xGMI; `value`
     # is computed from their sum, and the sum must be what the launches were asked to do.
     steps_per_rank, gather_via = gdist.gather_counts_rccl(m['steps_counted'], device)
     total_steps = sum(steps_per_rank)

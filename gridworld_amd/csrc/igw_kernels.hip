@@ -75,6 +75,9 @@ __device__ inline void stamp_features(const KParams&, unsigned long long) {}
 #ifndef IGW_SPLIT_BURST
 #define IGW_SPLIT_BURST 1
 #endif
+#ifndef IGW_EARLY_COUNTERS
+#define IGW_EARLY_COUNTERS 1
+#endif
 #ifndef IGW_STEPS_MODE
 #define IGW_STEPS_MODE 2
 #endif
@@ -1276,8 +1279,13 @@ __device__ inline void tail_step(const Grp<GS>& G, const KParams& p, const ActIn
         }
     };
     const auto counters = [&]() {   // one branch for the wavefronts with nothing to count, scalar counts from one lane otherwise
+#if IGW_EARLY_COUNTERS
+        const uint64_t m_need = 0, m_cell = 0;   // (added where they became known: step_kernel)
+        const uint64_t m_reset = __ballot(do_reset && G.gl == 0);
+#else
         const uint64_t m_need = __ballot(need && active && G.gl == 0), m_cell = __ballot(ch.idx >= 0 && active && G.gl == 0),
                        m_reset = __ballot(do_reset && G.gl == 0);
+#endif
         // IGW_STAT_STEPS: the env-steps of the launch -- the device-side count of the work a launch did (bench.py gathers
         // its per-rank delta over RCCL).  Added ONCE PER LAUNCH, by the first wavefront of block 0 (a scalar condition;
         // n_envs is read from the kernarg segment inside the branch).  Round 5 added it once per BLOCK: the first
@@ -1587,6 +1595,15 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
         }
     }
     const TailParams tp = tail_params(kernarg_again<STEP_KERNARG_HEAD>(p));
+#if IGW_EARLY_COUNTERS
+    // The event counters of a wavefront with changed envs are added HERE and behind the physics, not at the end of the
+    // step: a wavefront is not retired before its atomics are acknowledged, and at the end of the step that wait -- an L2
+    // round trip on a line sixteen blocks share -- was the last thing two wavefronts in three did (same-box A/B with the
+    // counters compiled out: -5 % walking, -3.7 % CDM, -3.2 % flying; profiles/r06_ab_variants.txt).  Issued early, the
+    // acknowledgements arrive while the wavefront computes.  IGW_STAT_RESCANS: env-steps that changed a cell.
+    if (chg_mask != 0 && tp.stats != nullptr && G.lane == 0)
+        counter_add(tp.stats + (blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + IGW_STAT_RESCANS, (unsigned long long)__builtin_popcountll(chg_mask));
+#endif
     prio_at<true, 3>(boost);
     if (MODE == MODE_FLY) world_update<GS, MODE_FLY, true>(G, p, e, occ_s, mv, boost);
     else world_update<GS, MODE_WALK, true>(G, p, e, occ_s, mv, boost);
@@ -1613,9 +1630,16 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
         env_store(e, p.agent + env);
     }
     stamp(p, 4);
-    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch, start_val, occ_wave_s);
     const int size_new = e.prev_size + syn_size_delta(ch, start_val);  // synthetic grid = grid - start (env.py:290)
     const bool need = size_new != e.prev_size;  // wrong_placement != 0 -> recompute (tasks/task.py:112)
+#if IGW_EARLY_COUNTERS
+    if (chg_mask != 0) {   // IGW_STAT_CHANGED: env-steps whose block count changed (see above: in front of the histogram update)
+        const uint64_t m_need = __ballot(need && active && G.gl == 0);
+        if (m_need != 0 && tp.stats != nullptr && G.lane == 0)
+            counter_add(tp.stats + (blockIdx.x & (IGW_STAT_STRIPES - 1)) * 8 + IGW_STAT_CHANGED, (unsigned long long)__builtin_popcountll(m_need));
+    }
+#endif
+    const int hmax = resolve_changes<GS, false>(G, p, sh.ws[wave], chg_mask, env_r, task, ch, start_val, occ_wave_s);
     int mi = e.max_int;
     if (changed) {
         if (need) {  // max_int = maximal_intersection(grid)

@@ -78,8 +78,9 @@ extern "C" {
 #define IGW_STAT_STRIPES 64
 #define IGW_STAT_CHANGED 0 /* env-steps whose block count changed (max_intersection recomputed) */
 #define IGW_STAT_RESETS 1  /* auto-resets performed */
-#define IGW_STAT_STEPS 2   /* env-steps executed: every step launch adds its envs (once per block), the fused
-                            * rollouts add T per env -- the device-side count of the work done */
+#define IGW_STAT_STEPS 2   /* env-steps executed: every step launch adds its num_envs (ONE atomic per launch: the first
+                            * wavefront of block 0, stripe 0), the fused rollouts add T per env -- the device-side count of
+                            * the work done */
 #define IGW_STAT_RESCANS 3 /* histogram row updates (env-steps that changed a cell; each takes the row maximum) */
 #define IGW_STAT_BAD_POSE 4   /* task rows whose init_pose was rejected (non-finite, |x| or |z| > 10, |y| > 64,
                                * |yaw| or |pitch| > 1e6) and replaced by the default pose */
