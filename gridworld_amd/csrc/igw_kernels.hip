@@ -1408,9 +1408,10 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     // Every load the step needs before it can compute -- occupancy row, agent record, task index, action -- is
     // issued before the first wait: one memory round trip.
     OccStage<GS> occ_in = {};
-#if !IGW_SPLIT_BURST
-    if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);  // diag 32: what the occupancy rows cost in the load burst
-#endif
+    constexpr bool SPLIT = IGW_SPLIT_BURST && GS == 4;   // (four-lane groups: "Split burst" below; the other widths: occupancy first, one wait)
+    if constexpr (!SPLIT) {
+        if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);  // diag 32: what the occupancy rows cost in the load burst
+    }
     // The agent record: with four or more lanes per env, lane q of a quad fetches the 16-byte piece q and the quad
     // hands the pieces round by DPP after the wait -- ONE dwordx4 per lane instead of four.  (All four lanes reading
     // the whole record is one cache line per env either way, but the CU's address pipe handles a wavefront's
@@ -1435,13 +1436,13 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
     if constexpr (FLY_SPREAD) load_fly_spread<GS>(ah, env_r, G.gl, ra);
     else ra = load_action<MODE>(ah, env_r);
     int8_t* grid_g = p.grid + (size_t)env_r * STRIDE;
-#if IGW_SPLIT_BURST
     // Split burst (four-lane groups): the SMALL loads (agent record piece, aux word, action: 24-28 bytes per lane) are
     // issued FIRST and waited for alone -- loads return in order, so s_waitcnt vmcnt(3) -- and the record unpack, the
     // action parse and the camera / heading arithmetic run while the three occupancy pieces (48 bytes per lane, 70 % of
     // the burst) are still on their way; the occupancy words go to LDS behind world_act_pre, in front of the ray march.
-    if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);
-#endif
+    if constexpr (SPLIT) {
+        if (!IGW_DIAG_FLAG(p, 32)) occ_issue<GS>(h_occ, G, env_r, occ_in);
+    }
     occ_commit_const<GS>(occ_wave_s);   // (LDS writes that need no load: in the shadow of the burst)
 #if defined(__HIP_DEVICE_COMPILE__) && IGW_SPLIT_BURST
     if constexpr (GS == 4) {   // the first wait: the small loads only
@@ -1469,7 +1470,6 @@ __global__ __launch_bounds__(BLOCK, (GS >= 4 ? 4 : 2)) void step_kernel(const ui
             asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2) : "v"(aux_w), "v"(ra.buttons.x), "v"(ra.f[3]), "v"(ra.f[4]), "v"(rec_piece.x), "v"(rec_piece.y), "v"(rec_piece.z), "v"(rec_piece.w));
     }
 #endif
-    constexpr bool SPLIT = IGW_SPLIT_BURST && GS == 4;   // (the occupancy words go to LDS behind world_act_pre)
     if constexpr (!SPLIT) occ_commit_var<GS>(G, occ_in, occ_s);
     if constexpr (REC_SPREAD) {  // piece 0: x, y | 1: z, yaw | 2: pitch, vy | 3: inventory, step_no, pack (include/igw.h)
         uint32_t w[16];
