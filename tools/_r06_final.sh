@@ -1,17 +1,20 @@
-export TMPDIR=/tmp IGW_GIT_COMMIT=3c35c63
+export TMPDIR=/tmp IGW_GIT_COMMIT=41fc689
 A="--no-cpu-baseline --no-fused --no-async --no-secondary --no-api --windows 3 --rehearsals 1 --steps 200 --warmup 20"
 tools/profile_gpu.sh r06 "$A" > gpurun_out/profile_r06.log 2>&1
 tools/profile_gpu.sh r06_flying "$A --mode flying" > gpurun_out/profile_r06_flying.log 2>&1
 tools/profile_gpu.sh r06_cdm "$A --workload cdm" > gpurun_out/profile_r06_cdm.log 2>&1
 tools/profile_gpu.sh r06_large "--no-cpu-baseline --no-fused --no-async --no-secondary --no-api --windows 2 --rehearsals 1 --steps 20 --warmup 5 --envs-per-gpu 2097152" > gpurun_out/profile_r06_large.log 2>&1
 ls gpurun_out/profiles_r06*/
-python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_r06_20steps.json 2> gpurun_out/bench_r06_20.err
+mkdir -p profiles_tmp; for t in r06 r06_flying r06_cdm r06_large; do cp gpurun_out/profiles_$t/${t}_*.json gpurun_out/profiles_$t/${t}_kernel_stats.csv profiles/; done
+( time python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_r06_20steps.json 2> gpurun_out/bench_r06_20.err ) 2> gpurun_out/bench_r06_20.time
+cat gpurun_out/bench_r06_20.time
+python3 bench.py --lanes-per-env 64 --no-secondary --no-cpu-baseline --no-api --no-fused --steps 100 --windows 5 --sweep '' > gpurun_out/bench_r06_lanes64.json 2> gpurun_out/bench_r06_lanes64.err
 python3 bench.py > gpurun_out/bench_r06.json 2> gpurun_out/bench_r06.err
 python3 bench.py --mode flying --no-cpu-baseline > gpurun_out/bench_r06_flying.json 2> gpurun_out/bench_r06_flying.err
 python3 bench.py --workload cdm --no-cpu-baseline > gpurun_out/bench_r06_cdm.json 2> gpurun_out/bench_r06_cdm.err
 python3 -c "
 import json
-for f in ('bench_r06_20steps','bench_r06','bench_r06_flying','bench_r06_cdm'):
+for f in ('bench_r06_20steps','bench_r06','bench_r06_flying','bench_r06_cdm','bench_r06_lanes64'):
     d=json.loads([l for l in open('gpurun_out/'+f+'.json').read().splitlines() if l.startswith('{')][-1])
     print(f, '%.3f G' % (d['value']/1e9), 'ms/step %.5f' % d['ms_per_step'], 'kernel %.3f us' % (d['roofline']['kernel_avg_ms']*1e3), 'spread', d['config']['window_spread'], d['config']['window_spread_p10_p90'])
 "
