@@ -28,19 +28,22 @@ buffers, so the captured graph stays valid; untimed), so no pass replays an acti
 MEDIAN window (max over ranks per window); every window is listed in config.windows_ms_per_step.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
-  roofline     -- the dominant kernel against the HBM roofline: `achieved` / `frac` from the ALGORITHMIC bytes per
-                  env-step of SURVEY.md section 8d (1274 + 1106 * p: the int8 grid streamed every step) over the
-                  kernel's average duration measured in this run (HIP events on the launch stream), and next to it
-                  what THIS design has to move (`design_bytes_per_env_step`: the 192-byte occupancy bitmap instead of
-                  the grid, ...) as `frac_design`; `traffic` = PMC bytes of the committed profile.  Fields that come
-                  from a committed profile instead of this run are listed in `from_profile`;
-  issue        -- the instruction-issue side (the real limiter): VALU instructions per wave from
-                  the committed SQ counter profile over THIS run's kernel time -> VALU issue utilisation;
+  roofline     -- what bounds the dominant kernel: top level `bound: "issue"`, `achieved` = `frac` = VALU issue
+                  utilisation (VALU instructions per wavefront of the committed SQ profile x wavefronts per SIMD x 4
+                  cycles over the kernel's average duration measured in THIS run with HIP events on the launch stream),
+                  `traffic` = PMC bytes per launch of the committed rocprofv3 profile; `roofline.hbm` = those bytes over
+                  the run's kernel time against the 8 TB/s (with `design_bytes_per_env_step`, `wasted_traffic`, the
+                  SURVEY 8(d) convention figure and a note on what the counters count at this batch size);
+                  `roofline.issue` = the SQ counters behind the top level.  Profiles carry the build id of the library
+                  they were taken with: `stale` says whether that is the library being timed;
   cpu_baseline -- the CPU oracle (plain-C port of the reference algorithm) timed on the host cores on bounded
                   samples: the headline workload on all usable cores and on one, BASELINE configs[0] (1 env,
-                  DUMMY_TASK-equivalent, 1,000 random steps, 1 core) and configs[3] (flying) (N = 1 only);
-  config.flying / config.cdm -- secondary measurements of the same window machinery in the default single-GPU run:
-                  BASELINE configs[3] (flying action space) and the real IGLU targets with partial starting grids.
+                  DUMMY_TASK-equivalent, 1,000 random steps, 1 core) and configs[3] (flying); on rank 0 at every N;
+  config.flying / config.cdm / config.small / config.facade_1env -- secondary measurements of the same window
+                  machinery in the default single-GPU run: BASELINE configs[3], the real IGLU targets with partial
+                  starting grids, configs[1] (4,096 envs) and configs[0] through the 1-env gym facade;
+  config.sweep / config.large -- the headline workload at larger batches per GPU (envs per GPU is a tunable), the
+                  largest (2,097,152 envs: beyond the Infinity Cache) with its own PMC profile: the HBM-bound regime.
 """
 import argparse
 import ctypes
