@@ -60,3 +60,35 @@ def test_committed_profiles_are_of_the_committed_kernels():
         s = json.load(open(f))
         if s.get('build_id'):
             assert s.get('git_commit'), f
+
+
+def test_roofline_object_names_the_bound_and_keeps_the_hbm_side(tmp_path):
+    """bench.roofline_of on the CPU (fake measurements, fake profile summaries): with an SQ profile of the timed build the
+    top level says `issue` with achieved = VALU instructions per wavefront x wavefronts per SIMD x 4 cycles over the run's
+    kernel time, the PMC traffic fraction sits under `hbm` with its Infinity-Cache note, and the 2,097,152-env batch
+    (`kind='large'`) takes its own profile unscaled; without an SQ profile the HBM object stands alone."""
+    import types
+    import bench
+    from gridworld_amd import _lib
+    d = str(tmp_path)
+    bid = _lib.build_id()
+    _write(d, 'r09_traffic.json', build_id=bid, git_commit='abc', hbm_bytes_per_launch=40.0e6, envs=65536, kernel_avg_ns=10000.0)
+    _write(d, 'r09_issue.json', build_id=bid, valu_insts_per_wave=960.0, salu_insts_per_wave=300.0, kernel_avg_ns=10000.0)
+    _write(d, 'r09_large_traffic.json', build_id=bid, git_commit='abc', hbm_bytes_per_launch=1.28e9, envs=2097152, kernel_avg_ns=280000.0)
+    m = dict(kernel_ms=0.010, p_changed=0.0625, p_cell_changed=0.0625, resets_in_window=262 * 20)
+    r = types.SimpleNamespace(N=65536, K=20, flying=False, workload='rt20')
+    roof, iss = bench.roofline_of(r, m, 4, profiles_dir=d)
+    assert roof['bound'] == 'issue' and roof['unit'].startswith('VALU issue cycles') and roof['stale'] is False
+    assert abs(roof['achieved'] - 960.0 * 4 * 4 / (10e-6 * 2.4e9)) < 1e-9 and roof['frac'] == roof['achieved'] and roof['peak'] == 1.0
+    hbm = roof['hbm']
+    assert hbm['bound'] == 'hbm' and hbm['peak'] == 8000.0 and roof['traffic'] == hbm['traffic'] == 40.0e6
+    assert abs(hbm['frac'] - 40.0e6 / 10e-6 / 1e9 / 8000.0) < 1e-12 and 'Infinity Cache' in hbm['note'] and 'fits' in hbm['note']
+    assert roof['issue'] is iss and iss['stale'] is False
+    # the large batch: its own profile (not the 65,536-env one scaled), DRAM regime in the note, no SQ profile of that kind
+    rl = types.SimpleNamespace(N=2097152, K=20, flying=False, workload='rt20')
+    ml = dict(kernel_ms=0.270, p_changed=0.0625, p_cell_changed=0.0625, resets_in_window=8400 * 20)
+    big, iss_l = bench.roofline_of(rl, ml, 4, profiles_dir=d, kind='large')
+    assert iss_l is None and big['bound'] == 'hbm' and big['traffic'] == 1.28e9 and 'exceeds' in big['note']
+    assert abs(big['frac'] - 1.28e9 / 270e-6 / 1e9 / 8000.0) < 1e-12
+    slim = bench.slim_roofline(roof)
+    assert slim['bound'] == 'issue' and slim['hbm']['bound'] == 'hbm' and 'convention' not in slim['hbm']
